@@ -1,0 +1,194 @@
+/*
+ * spsparse_amd.h -- C ABI of the MI355X SpGEMM behind spsparse::multiply().
+ *
+ * This is the drop-in boundary.  The reference has no FFI today: its boundary
+ * is the header-only template spsparse::multiply()
+ * (slib/spsparse/multiply_sparse.hpp:138-164).  include/spsparse_amd/multiply.hpp
+ * is that template re-stated on top of the entry points below; INTEGRATION.md
+ * shows the lines a spsparse maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++ or torch types; never throws.
+ *   - every entry point returns 0 or a negative SPSAMD_E* code; the text of the
+ *     last error of a context is at spsamd_last_error().  The C++ shim forwards
+ *     it to (*spsparse_error)(-1, "%s", msg) (spsparse.hpp:47,54).
+ *   - indices int32, values double: the only instantiation the reference tests
+ *     (tests/test_multiply_sparse.cpp:90-91).  Counts and offsets are 64 bit:
+ *     nnz(C) exceeds 2^31 on BASELINE cfg2.
+ *   - operands are borrowed for the duration of a call and never modified
+ *     (multiply_sparse.hpp:143,146 take const&).
+ *   - one context = one device + one HIP stream + one workspace; calls on
+ *     different contexts may run concurrently from different host threads.
+ *   - there is no CPU fallback: every compute entry point needs the GPU.
+ */
+#ifndef SPSPARSE_AMD_H
+#define SPSPARSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes */
+#define SPSAMD_OK            0
+#define SPSAMD_EDIM        (-1)   /* inner dimensions differ (multiply_sparse.hpp:172-174) */
+#define SPSAMD_EINVAL      (-2)   /* bad argument (null pointer, index out of bounds, unsorted scale vector ...) */
+#define SPSAMD_EHIP        (-3)   /* HIP runtime error (message carries hipGetErrorString) */
+#define SPSAMD_ENOMEM      (-4)   /* device or host allocation failed */
+#define SPSAMD_ECAPACITY   (-5)   /* caller-supplied output buffer too small */
+#define SPSAMD_ENODEVICE   (-6)   /* no usable gfx950 device */
+
+/* spsparse::DuplicatePolicy (spsparse.hpp:25-26), same enumerator order */
+#define SPSAMD_LEAVE_ALONE 0
+#define SPSAMD_ADD         1
+#define SPSAMD_REPLACE     2
+
+/* where the pointers of an operand live */
+#define SPSAMD_MEM_HOST    0
+#define SPSAMD_MEM_DEVICE  1
+
+typedef struct spsamd_ctx spsamd_ctx;
+
+/*
+ * A COO matrix as VectorCooArray<int,double,2> stores it
+ * (VectorCooArray.hpp:17,22-23,35): one index vector per dimension, one value
+ * vector, shape, and sort_order[0] (-1 = unsorted / edit mode, 0 = consolidated
+ * row major {0,1}, 1 = consolidated column major {1,0}).  A matching
+ * sort order is trusted like Consolidate<> does (algorithm.hpp:360).
+ */
+typedef struct {
+	const int32_t *idx0;
+	const int32_t *idx1;
+	const double *val;
+	size_t nnz;
+	size_t shape0, shape1;
+	int sort0;
+	int mem;             /* SPSAMD_MEM_HOST or SPSAMD_MEM_DEVICE */
+} spsamd_coo;
+
+/*
+ * A sparse vector (VectorCooArray<int,double,1>): the three diagonal scale
+ * operands and the right-hand side of the matrix-vector multiply.  Scale
+ * vectors must be strictly ascending in idx: the reference joins them as
+ * stored and silently mis-computes otherwise (multiply_sparse.hpp:83-85,
+ * 223-226) -- this library rejects them (SPSAMD_EINVAL).
+ */
+typedef struct {
+	const int32_t *idx;
+	const double *val;
+	size_t nnz;
+	size_t shape0;
+	int sort0;           /* only read for the MV right-hand side */
+	int mem;
+} spsamd_vec;
+
+/* ---- sinks: the device side of the Accumulator concept (accum.hpp:12-24) ---- */
+
+#define SPSAMD_SINK_COO       1   /* row-major sorted (i, j, v) tuples in device memory */
+#define SPSAMD_SINK_DIGEST    2   /* count + sum + index hash only (ScalarAccumulator analogue, accum.hpp:158-167) */
+
+/* sink flags */
+#define SPSAMD_SINK_ROWSTATS  1   /* DIGEST: also fill row_nnz / row_sum (length = rows of op(A)) */
+
+/*
+ * Result of one multiply.  For SINK_COO the three arrays live in the context's
+ * output buffer (device memory) and stay valid until the next multiply or
+ * spsamd_ctx_destroy on that context; tuples are in ascending (i, j), each
+ * (i, j) at most once, exact zeros dropped (multiply_sparse.hpp:238).
+ */
+typedef struct {
+	uint64_t shape0, shape1;      /* ret.set_shape(), multiply_sparse.hpp:169 */
+	uint64_t nnz;                 /* tuples emitted */
+	uint64_t products;            /* P = sum over A tuples of the B row length */
+	uint64_t nnz_a, nnz_b;        /* consolidated operand sizes */
+	double sum;                   /* DIGEST: sum of emitted values */
+	uint64_t hash;                /* DIGEST: sum of mix64(i, j) mod 2^64 */
+	const int32_t *idx0;          /* COO: device pointers */
+	const int32_t *idx1;
+	const double *val;
+	const int64_t *row_nnz;       /* DIGEST|ROWSTATS: device pointers */
+	const double *row_sum;
+	/* timing of the device pipeline stages, milliseconds (HIP events) */
+	float ms_consolidate, ms_symbolic, ms_numeric, ms_total;
+	/* numeric kernels by row class (P_r = products of the output row):
+	 * light P_r <= 64, mid <= 4096, heavy above */
+	float ms_light, ms_mid, ms_heavy;
+	uint64_t rows_light, rows_mid, rows_heavy;
+	uint64_t products_light, products_mid, products_heavy;
+} spsamd_result;
+
+/* ---- context ---- */
+
+/* device < 0: current device.  stream: a hipStream_t to run on, or NULL to
+ * create a private one.  Fails with SPSAMD_ENODEVICE without a GPU. */
+int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream);
+void spsamd_ctx_destroy(spsamd_ctx *ctx);
+const char *spsamd_last_error(const spsamd_ctx *ctx);
+/* pre-size the workspace (bytes); optional, it grows on demand otherwise */
+int spsamd_ctx_reserve(spsamd_ctx *ctx, size_t workspace_bytes, size_t output_tuples);
+const char *spsamd_version(void);
+
+/*
+ * ret = C * diag(scalei) * op(A) * diag(scalej) * op(B) * diag(scalek)
+ * -- spsparse::multiply, matrix x matrix (multiply_sparse.hpp:152-248).
+ * Argument order and meaning follow the reference; scale pointers may be NULL;
+ * only the exact character 'T' transposes (multiply_sparse.hpp:167-168).
+ * Operands may be host or device resident (per-operand `mem`).  The result
+ * goes to the device sink named by sink_kind; host callers then use
+ * spsamd_result_fetch() to stream it out in order.
+ */
+int spsamd_multiply(spsamd_ctx *ctx, double C,
+	const spsamd_vec *scalei,
+	const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej,
+	const spsamd_coo *B, char transpose_B,
+	const spsamd_vec *scalek,
+	int duplicate_policy, int zero_nan,
+	int sink_kind, int sink_flags,
+	spsamd_result *result);
+
+/*
+ * Host delivery of the last SINK_COO result of ctx: calls cb(user, i, j, v, n)
+ * with consecutive chunks (host pointers, valid during the call) in ascending
+ * (i, j) order -- the shim's callback loops ret.add({i,j}, v)
+ * (multiply_sparse.hpp:242).  A non-zero return of cb stops the delivery and
+ * is returned.
+ */
+typedef int (*spsamd_chunk_fn)(void *user, const int32_t *i, const int32_t *j,
+	const double *v, size_t n);
+int spsamd_result_fetch(spsamd_ctx *ctx, const spsamd_result *result,
+	spsamd_chunk_fn cb, void *user);
+
+/* Copy `bytes` from device memory of this context's device (e.g. result->row_nnz)
+ * to host memory, ordered after everything queued on the context's stream. */
+int spsamd_copy_to_host(spsamd_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/*
+ * Stand-alone consolidate (algorithm.hpp:251-319) of a COO matrix on the
+ * device: stable sort by sort_order {so0, 1-so0}, zeros dropped, duplicates
+ * merged by policy.  Output tuples land in the context's output buffer
+ * (result->idx0/idx1/val, nnz); fetch them with spsamd_result_fetch.
+ */
+int spsamd_consolidate(spsamd_ctx *ctx, const spsamd_coo *A, int so0,
+	int duplicate_policy, int zero_nan, spsamd_result *result);
+
+/* ---- synthetic operands generated on the device (bench / tests) ----
+ * Bit-identical to spsparse_amd/workloads.py.  Outputs are device arrays
+ * owned by the caller (capacity >= the generator's tuple count). */
+int spsamd_gen_rmat(spsamd_ctx *ctx, int scale, int edge_factor, uint64_t seed,
+	uint64_t first_edge, uint64_t n_edges, int32_t *idx0, int32_t *idx1, double *val);
+int spsamd_gen_random_rows(spsamd_ctx *ctx, uint64_t n, uint64_t per_row, uint64_t seed,
+	uint64_t stream_base, int32_t *idx0, int32_t *idx1, double *val);
+/* 5-point Poisson on an N x N grid: writes 5N^2-4N tuples, row-major sorted */
+int spsamd_gen_poisson2d(spsamd_ctx *ctx, uint64_t N, int32_t *idx0, int32_t *idx1, double *val);
+/* 7-point Laplacian on an N^3 grid: writes 7N^3-6N^2 tuples, row-major sorted */
+int spsamd_gen_laplace3d(spsamd_ctx *ctx, uint64_t N, int32_t *idx0, int32_t *idx1, double *val);
+/* 2x2x2 piecewise-constant aggregation, (N/2)^3 x N^3: writes N^3 tuples */
+int spsamd_gen_aggregation3d(spsamd_ctx *ctx, uint64_t N, int32_t *idx0, int32_t *idx1, double *val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

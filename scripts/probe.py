@@ -1,0 +1,43 @@
+"""Developer probe: time the device pipeline on a synthetic operand (not the bench)."""
+import sys
+import time
+
+import torch
+
+from spsparse_amd import capi
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "rmat"
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    sink = capi.SINK_COO if (len(sys.argv) > 3 and sys.argv[3] == "coo") else capi.SINK_DIGEST
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    dev = torch.device("cuda:0")
+    ctx = capi.Context()
+    if kind == "rmat":
+        n, ne = 1 << size, 16 << size
+    elif kind == "poisson":
+        n, ne = size * size, 5 * size * size - 4 * size
+    t0 = torch.empty(ne, dtype=torch.int32, device=dev)
+    t1 = torch.empty(ne, dtype=torch.int32, device=dev)
+    tv = torch.empty(ne, dtype=torch.float64, device=dev)
+    if kind == "rmat":
+        ctx.gen_rmat(size, 1, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+    else:
+        ctx.gen_poisson2d(size, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+    torch.cuda.synchronize()
+    A = capi.device_coo(t0.data_ptr(), t1.data_ptr(), tv.data_ptr(), ne, (n, n))
+    for rep in range(reps):
+        t = time.time()
+        r = ctx.multiply(A, A, sink=sink)
+        dt = time.time() - t
+        print("%s %d rep %d: wall %.1f ms | total %.2f cons %.2f symb %.2f num %.2f (light %.2f mid %.2f heavy %.2f) | "
+              "nnzA %d P %d nnzC %d | rows l/m/h %d/%d/%d prods l/m/h %.3g/%.3g/%.3g | %.3g prod/s alg-read %.1f GB/s" % (
+                  kind, size, rep, dt * 1e3, r.ms_total, r.ms_consolidate, r.ms_symbolic, r.ms_numeric, r.ms_light, r.ms_mid,
+                  r.ms_heavy, r.nnz_a, r.products, r.nnz, r.rows_light, r.rows_mid, r.rows_heavy,
+                  r.products_light, r.products_mid, r.products_heavy, r.products / (r.ms_total * 1e-3),
+                  (16 * r.nnz_a + 12 * r.products) / (r.ms_total * 1e-3) / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()

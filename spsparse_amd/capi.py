@@ -1,0 +1,206 @@
+"""ctypes binding of libspsparse_amd.so -- the C ABI in include/spsparse_amd.h.
+
+Thin marshalling only: numpy arrays (host operands) or raw device pointers
+(e.g. torch tensors' data_ptr()) go in, the library's result struct comes out.
+There is no CPU fallback: if the shared library is missing or no MI355X is
+visible this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspsparse_amd.so")
+
+LEAVE_ALONE, ADD, REPLACE = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+SINK_COO, SINK_DIGEST = 1, 2
+SINK_ROWSTATS = 1
+
+ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE"}
+
+
+class SpsamdError(RuntimeError):
+    """A negative return code of the C ABI (the shim's (*spsparse_error)(-1, msg))."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class Coo(C.Structure):
+    _fields_ = [("idx0", C.c_void_p), ("idx1", C.c_void_p), ("val", C.c_void_p), ("nnz", C.c_size_t),
+                ("shape0", C.c_size_t), ("shape1", C.c_size_t), ("sort0", C.c_int), ("mem", C.c_int)]
+
+
+class Vec(C.Structure):
+    _fields_ = [("idx", C.c_void_p), ("val", C.c_void_p), ("nnz", C.c_size_t), ("shape0", C.c_size_t),
+                ("sort0", C.c_int), ("mem", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("shape0", C.c_uint64), ("shape1", C.c_uint64), ("nnz", C.c_uint64), ("products", C.c_uint64),
+                ("nnz_a", C.c_uint64), ("nnz_b", C.c_uint64), ("sum", C.c_double), ("hash", C.c_uint64),
+                ("idx0", C.c_void_p), ("idx1", C.c_void_p), ("val", C.c_void_p),
+                ("row_nnz", C.c_void_p), ("row_sum", C.c_void_p),
+                ("ms_consolidate", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float),
+                ("ms_total", C.c_float), ("ms_light", C.c_float), ("ms_mid", C.c_float), ("ms_heavy", C.c_float),
+                ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
+                ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64)]
+
+
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_size_t)
+
+# every symbol include/spsparse_amd.h declares
+SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
+           "spsamd_multiply", "spsamd_result_fetch", "spsamd_copy_to_host", "spsamd_consolidate", "spsamd_gen_rmat",
+           "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libspsparse_amd.so is not built: run `python -m spsparse_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    if os.environ.get("SPSAMD_NO_TORCH") != "1":
+        # PyTorch wheels bundle their own HIP runtime under the same SONAME
+        # (libamdhip64.so.7).  Two runtimes in one process cannot both own the
+        # GPU, so when torch is installed it is imported FIRST: the loader then
+        # binds this library to the runtime torch already brought in.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.spsamd_ctx_create.argtypes = [P(C.c_void_p), C.c_int, C.c_void_p]
+    L.spsamd_ctx_destroy.argtypes = [C.c_void_p]
+    L.spsamd_ctx_destroy.restype = None
+    L.spsamd_last_error.argtypes = [C.c_void_p]
+    L.spsamd_last_error.restype = C.c_char_p
+    L.spsamd_ctx_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    L.spsamd_version.restype = C.c_char_p
+    L.spsamd_multiply.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Coo), C.c_char, P(Vec),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
+    L.spsamd_result_fetch.argtypes = [C.c_void_p, P(Result), CHUNK_FN, C.c_void_p]
+    L.spsamd_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.spsamd_consolidate.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_int, C.c_int, P(Result)]
+    L.spsamd_gen_rmat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spsamd_gen_random_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def host_coo(idx0, idx1, val, shape, sort0=-1):
+    """Coo struct over numpy arrays; returns (struct, keepalive)."""
+    a0 = np.ascontiguousarray(idx0, dtype=np.int32)
+    a1 = np.ascontiguousarray(idx1, dtype=np.int32)
+    av = np.ascontiguousarray(val, dtype=np.float64)
+    assert a0.shape == a1.shape == av.shape
+    return Coo(a0.ctypes.data, a1.ctypes.data, av.ctypes.data, av.size, int(shape[0]), int(shape[1]), sort0, MEM_HOST), (a0, a1, av)
+
+
+def device_coo(ptr0, ptr1, ptrv, nnz, shape, sort0=-1):
+    return Coo(ptr0, ptr1, ptrv, nnz, int(shape[0]), int(shape[1]), sort0, MEM_DEVICE)
+
+
+def host_vec(idx, val, shape0, sort0=-1):
+    a = np.ascontiguousarray(idx, dtype=np.int32)
+    v = np.ascontiguousarray(val, dtype=np.float64)
+    return Vec(a.ctypes.data, v.ctypes.data, v.size, int(shape0), sort0, MEM_HOST), (a, v)
+
+
+class Context:
+    """One device + stream + workspace (spsamd_ctx)."""
+
+    def __init__(self, device=-1, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.spsamd_ctx_create(C.byref(h), device, stream)
+        if rc != 0:
+            raise SpsamdError(rc, "spsamd_ctx_create failed (no MI355X visible?)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.spsamd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SpsamdError(rc, self.L.spsamd_last_error(self.h).decode())
+
+    def reserve(self, workspace_bytes=0, output_tuples=0):
+        self._check(self.L.spsamd_ctx_reserve(self.h, workspace_bytes, output_tuples))
+
+    def multiply(self, A, B, C_=1.0, scalei=None, tA='.', scalej=None, tB='.', scalek=None,
+                 duplicate_policy=ADD, zero_nan=False, sink=SINK_COO, flags=0):
+        """spsamd_multiply.  A, B: Coo structs; scale*: Vec structs or None."""
+        res = Result()
+        ptr = [None if s is None else C.byref(s) for s in (scalei, scalej, scalek)]
+        rc = self.L.spsamd_multiply(self.h, float(C_), ptr[0], C.byref(A), tA.encode(), ptr[1], C.byref(B),
+                                    tB.encode(), ptr[2], duplicate_policy, int(zero_nan), sink, flags, C.byref(res))
+        self._check(rc)
+        return res
+
+    def consolidate(self, A, so0, duplicate_policy=ADD, zero_nan=False):
+        res = Result()
+        self._check(self.L.spsamd_consolidate(self.h, C.byref(A), so0, duplicate_policy, int(zero_nan), C.byref(res)))
+        return res
+
+    def fetch(self, res):
+        """Host copy of a SINK_COO result through spsamd_result_fetch: (i, j, v)."""
+        n = int(res.nnz)
+        oi, oj, ov = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+        pos = [0]
+
+        def cb(_user, pi, pj, pv, cnt):
+            o = pos[0]
+            oi[o:o + cnt] = np.ctypeslib.as_array(pi, shape=(cnt,))
+            oj[o:o + cnt] = np.ctypeslib.as_array(pj, shape=(cnt,))
+            ov[o:o + cnt] = np.ctypeslib.as_array(pv, shape=(cnt,))
+            pos[0] = o + cnt
+            return 0
+
+        self._check(self.L.spsamd_result_fetch(self.h, C.byref(res), CHUNK_FN(cb), None))
+        assert pos[0] == n
+        return oi, oj, ov
+
+    def to_host(self, dev_ptr, count, dtype):
+        """numpy copy of `count` elements of device memory (spsamd_copy_to_host)."""
+        out = np.empty(count, dtype=dtype)
+        self._check(self.L.spsamd_copy_to_host(self.h, out.ctypes.data, dev_ptr, out.nbytes))
+        return out
+
+    # ---- device generators (outputs: caller-owned device pointers)
+    def gen_rmat(self, scale, seed, first_edge, n_edges, p0, p1, pv, edge_factor=16):
+        self._check(self.L.spsamd_gen_rmat(self.h, scale, edge_factor, seed, first_edge, n_edges, p0, p1, pv))
+
+    def gen_random_rows(self, n, per_row, seed, stream_base, p0, p1, pv):
+        self._check(self.L.spsamd_gen_random_rows(self.h, n, per_row, seed, stream_base, p0, p1, pv))
+
+    def gen_poisson2d(self, N, p0, p1, pv):
+        self._check(self.L.spsamd_gen_poisson2d(self.h, N, p0, p1, pv))
+
+    def gen_laplace3d(self, N, p0, p1, pv):
+        self._check(self.L.spsamd_gen_laplace3d(self.h, N, p0, p1, pv))
+
+    def gen_aggregation3d(self, N, p0, p1, pv):
+        self._check(self.L.spsamd_gen_aggregation3d(self.h, N, p0, p1, pv))

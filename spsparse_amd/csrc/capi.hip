@@ -1,0 +1,198 @@
+// capi.hip -- the extern "C" boundary declared in include/spsparse_amd.h.
+// Argument handling mirrors spsparse::multiply (multiply_sparse.hpp:152-248):
+// shape first (:169), inner-dimension check (:172-174), short-circuits
+// (:178-184), consolidation of both operands (:187-188), then the product.
+#include "internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <exception>
+
+using namespace spsamd;
+
+#define API_GUARD(ctx, ...)                                                         \
+	try { __VA_ARGS__ }                                                             \
+	catch (const spsamd::Error &e) { (ctx)->last_error = e.msg; return e.code; }    \
+	catch (const std::bad_alloc &) { (ctx)->last_error = "host allocation failed"; return SPSAMD_ENOMEM; } \
+	catch (const std::exception &e) { (ctx)->last_error = e.what(); return SPSAMD_EINVAL; }
+
+extern "C" const char *spsamd_version(void) { return "spsparse_amd 0.1 (gfx950)"; }
+
+extern "C" int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream)
+{
+	if (!out) return SPSAMD_EINVAL;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return SPSAMD_ENODEVICE; }
+	if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return SPSAMD_ENODEVICE; }
+	if (device >= ndev) return SPSAMD_ENODEVICE;
+	if (hipSetDevice(device) != hipSuccess) return SPSAMD_ENODEVICE;
+	spsamd_ctx *c = new (std::nothrow) spsamd_ctx();
+	if (!c) return SPSAMD_ENOMEM;
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+	if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+	else {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SPSAMD_EHIP; }
+		c->own_stream = true;
+	}
+	for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return SPSAMD_EHIP; }
+	*out = c;
+	return SPSAMD_OK;
+}
+
+extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	c->arena.release();
+	c->out_i.release(); c->out_j.release(); c->out_v.release();
+	c->rowstat_n.release(); c->rowstat_s.release();
+	if (c->pinned) (void)hipHostFree(c->pinned);
+	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+	if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" const char *spsamd_last_error(const spsamd_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+
+extern "C" int spsamd_ctx_reserve(spsamd_ctx *c, size_t workspace_bytes, size_t output_tuples)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		SPS_HIP(hipSetDevice(c->device));
+		if (workspace_bytes) c->arena.reserve(workspace_bytes);
+		if (output_tuples) {
+			c->out_i.ensure(output_tuples * sizeof(int32_t));
+			c->out_j.ensure(output_tuples * sizeof(int32_t));
+			c->out_v.ensure(output_tuples * sizeof(double));
+		}
+		return SPSAMD_OK;
+	)
+}
+
+static bool same_operand(const spsamd_coo *a, const spsamd_coo *b)
+{
+	return a->idx0 == b->idx0 && a->idx1 == b->idx1 && a->val == b->val && a->nnz == b->nnz &&
+		a->shape0 == b->shape0 && a->shape1 == b->shape1 && a->sort0 == b->sort0 && a->mem == b->mem;
+}
+
+extern "C" int spsamd_multiply(spsamd_ctx *c, double C,
+	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
+	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,
+	int sink_kind, int sink_flags, spsamd_result *res)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!A || !B || !res) throw Error{SPSAMD_EINVAL, "null operand or result"};
+		if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+		if (sink_kind != SPSAMD_SINK_COO && sink_kind != SPSAMD_SINK_DIGEST) throw Error{SPSAMD_EINVAL, "bad sink_kind"};
+		std::memset(res, 0, sizeof(*res));
+		// multiply_sparse.hpp:167-169: op(A) rows = A.shape[a0]; op(B) is read by ROWS here
+		// (inner index first), its columns are B.shape[bj]
+		const int a0 = transpose_A == 'T' ? 1 : 0, a1 = 1 - a0;
+		const int bk = transpose_B == 'T' ? 1 : 0, bj = 1 - bk;
+		const size_t ashape[2] = {A->shape0, A->shape1}, bshape[2] = {B->shape0, B->shape1};
+		res->shape0 = ashape[a0];
+		res->shape1 = bshape[bj];
+		if (ashape[a1] != bshape[bk]) {                                  // :172-174
+			char buf[160];
+			std::snprintf(buf, sizeof buf, "Inner dimensions for A (%ld) and B (%ld) must match!", (long)ashape[a1], (long)bshape[bk]);
+			throw Error{SPSAMD_EDIM, buf};
+		}
+		if (C == 0 || (scalei && scalei->nnz == 0) || A->nnz == 0 || (scalej && scalej->nnz == 0) ||
+			B->nnz == 0 || (scalek && scalek->nnz == 0))                 // :178-184
+			return SPSAMD_OK;
+
+		SPS_HIP(hipSetDevice(c->device));
+		c->arena.reset();
+		hipStream_t st = c->stream;
+		SPS_HIP(hipEventRecord(c->ev[0], st));
+		MultiplyArgs a;
+		a.C = C; a.sink_kind = sink_kind; a.sink_flags = sink_flags;
+		consolidate_operand(c, A, a0, duplicate_policy, zero_nan, &a.A);          // :187
+		if (a0 == bk && same_operand(A, B)) a.B = a.A;                             // A*A: one consolidation serves both
+		else consolidate_operand(c, B, bk, duplicate_policy, zero_nan, &a.B);      // :188
+		upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
+		upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
+		upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
+		spgemm(c, a, res);
+		SPS_HIP(hipEventRecord(c->ev[7], st));
+		SPS_HIP(hipEventSynchronize(c->ev[7]));
+		if (res->nnz_a && res->nnz_b) {
+			SPS_HIP(hipEventElapsedTime(&res->ms_consolidate, c->ev[0], c->ev[1]));
+		}
+		SPS_HIP(hipEventElapsedTime(&res->ms_total, c->ev[0], c->ev[7]));
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_result_fetch(spsamd_ctx *c, const spsamd_result *res, spsamd_chunk_fn cb, void *user)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!res || !cb) throw Error{SPSAMD_EINVAL, "null result or callback"};
+		if (res->nnz == 0) return SPSAMD_OK;
+		if (!res->idx0 || !res->val) throw Error{SPSAMD_EINVAL, "result has no COO tuples (DIGEST sink?)"};
+		SPS_HIP(hipSetDevice(c->device));
+		const size_t chunk = size_t(1) << 20;
+		char *h = (char *)c->host_staging(chunk * 16);
+		int32_t *hi = (int32_t *)h, *hj = (int32_t *)(h + chunk * 4);
+		double *hv = (double *)(h + chunk * 8);
+		for (uint64_t o = 0; o < res->nnz; o += chunk) {
+			size_t n = (size_t)std::min<uint64_t>(chunk, res->nnz - o);
+			SPS_HIP(hipMemcpyAsync(hi, res->idx0 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
+			if (res->idx1) SPS_HIP(hipMemcpyAsync(hj, res->idx1 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipMemcpyAsync(hv, res->val + o, n * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipStreamSynchronize(c->stream));
+			int rc = cb(user, hi, res->idx1 ? hj : nullptr, hv, n);
+			if (rc) return rc;
+		}
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_copy_to_host(spsamd_ctx *c, void *dst, const void *src, size_t bytes)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (bytes && (!dst || !src)) throw Error{SPSAMD_EINVAL, "null pointer"};
+		SPS_HIP(hipSetDevice(c->device));
+		SPS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+		SPS_HIP(hipStreamSynchronize(c->stream));
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, int duplicate_policy, int zero_nan,
+	spsamd_result *res)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!A || !res || (so0 != 0 && so0 != 1)) throw Error{SPSAMD_EINVAL, "bad argument"};
+		if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+		std::memset(res, 0, sizeof(*res));
+		res->shape0 = A->shape0; res->shape1 = A->shape1;
+		if (A->nnz == 0) return SPSAMD_OK;
+		SPS_HIP(hipSetDevice(c->device));
+		c->arena.reset();
+		spsamd_coo X = *A;
+		X.sort0 = -1;                         // the stand-alone algorithm always runs (algorithm.hpp:251)
+		ConMat m;
+		consolidate_operand(c, &X, so0, duplicate_policy, zero_nan, &m);
+		size_t n = m.nnz;
+		c->out_i.ensure(n * 4 + 4); c->out_j.ensure(n * 4 + 4); c->out_v.ensure(n * 8 + 8);
+		// m.row is the leading (sorted) dimension: put dimensions back in place
+		int32_t *d0 = (int32_t *)c->out_i.p, *d1 = (int32_t *)c->out_j.p;
+		SPS_HIP(hipMemcpyAsync(so0 == 0 ? d0 : d1, m.row, n * 4, hipMemcpyDeviceToDevice, c->stream));
+		SPS_HIP(hipMemcpyAsync(so0 == 0 ? d1 : d0, m.col, n * 4, hipMemcpyDeviceToDevice, c->stream));
+		SPS_HIP(hipMemcpyAsync(c->out_v.p, m.val, n * 8, hipMemcpyDeviceToDevice, c->stream));
+		SPS_HIP(hipStreamSynchronize(c->stream));
+		res->nnz = n; res->nnz_a = n;
+		res->idx0 = d0; res->idx1 = d1; res->val = (double *)c->out_v.p;
+		return SPSAMD_OK;
+	)
+}

@@ -1,0 +1,290 @@
+// consolidate.hip -- device restatement of the operand canonicalisation that
+// spsparse::multiply runs before its loops:
+//   Consolidate<>          algorithm.hpp:353-369
+//   consolidate()          algorithm.hpp:251-319  (stable sort, zero drop, duplicate merge)
+//   sorted_permutation()   algorithm.hpp:411-427
+//   dim_beginnings()       algorithm.hpp:74-118
+// Data layout in HBM: SoA like VectorCooArray (one int32 array per dimension,
+// one f64 array), sorted by (row of op(X), col of op(X)).
+#include "internal.h"
+#include "devutil.h"
+
+namespace spsamd {
+
+static int bits_for(uint64_t dim)
+{
+	// bits needed to hold indices 0 .. dim-1
+	int b = 0;
+	while (b < 63 && (uint64_t(1) << b) < dim) ++b;
+	return b;
+}
+
+// flags: bit0 = an index is out of [0, shape); bit1 = not (strictly sorted, no zero values)
+__global__ void k_inspect(const int32_t *major, const int32_t *minor, const double *val, size_t n,
+	uint64_t nrow, uint64_t ncol, int zero_nan, uint32_t *flags)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int32_t r = major[i], c = minor[i];
+	uint32_t f = 0;
+	if (r < 0 || (uint64_t)r >= nrow || c < 0 || (uint64_t)c >= ncol) f |= 1u;
+	double v = val[i];
+	if (v == 0 || (zero_nan && v != v)) f |= 2u;
+	if (i > 0) {
+		int32_t pr = major[i - 1], pc = minor[i - 1];
+		if (!(pr < r || (pr == r && pc < c))) f |= 2u;
+	}
+	if (f) atomicOr(flags, f);
+}
+
+__global__ void k_build_keys(const int32_t *major, const int32_t *minor, size_t n, int minor_bits, uint64_t *keys)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) keys[i] = ((uint64_t)(uint32_t)major[i] << minor_bits) | (uint64_t)(uint32_t)minor[i];
+}
+
+// Gather the values into sorted order and flag the tuples consolidate() keeps:
+// zeros are skipped (algorithm.hpp:284-292).  With zero_nan the first kept
+// tuple is the first that is neither 0 nor NaN (algorithm.hpp:272-275): its
+// position is reduced into *first and applied by k_apply_first.
+__global__ void k_gather_flag(const double *val, const uint32_t *perm, size_t n, int zero_nan,
+	double *sval, uint8_t *keep, uint32_t *first)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	double v = val[perm[i]];
+	sval[i] = v;
+	keep[i] = (v != 0) ? 1 : 0;
+	if (zero_nan && v != 0 && v == v) atomicMin(first, (uint32_t)i);
+}
+
+__global__ void k_apply_first(uint8_t *keep, size_t n, const uint32_t *first)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && i < *first) keep[i] = 0;
+}
+
+__global__ void k_compact(const uint64_t *keys, const double *sval, const uint8_t *keep, const uint32_t *pos, size_t n,
+	uint64_t *kk, double *kv)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && keep[i]) {
+		uint32_t p = pos[i];
+		kk[p] = keys[i];
+		kv[p] = sval[i];
+	}
+}
+
+__global__ void k_heads(const uint64_t *kk, const uint32_t *nk_ptr, size_t n, uint8_t *head)
+{
+	size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	uint32_t nk = *nk_ptr;
+	head[j] = (j < nk && (j == 0 || kk[j] != kk[j - 1])) ? 1 : 0;
+}
+
+// One thread per distinct index: walks its run of equal keys in sorted (=
+// insertion, the sort is stable) order and applies the DuplicatePolicy
+// exactly as algorithm.hpp:306-310 does, left to right.
+__global__ void k_merge(const uint64_t *kk, const double *kv, const uint8_t *head, const uint32_t *hpos,
+	const uint32_t *nk_ptr, size_t n, int minor_bits, int policy,
+	int32_t *row, int32_t *col, double *val)
+{
+	size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n || !head[j]) return;
+	uint32_t nk = *nk_ptr;
+	uint64_t key = kk[j];
+	double acc = kv[j];
+	for (size_t t = j + 1; t < nk && kk[t] == key; ++t) {
+		if (policy == SPSAMD_ADD) acc += kv[t];
+		else if (policy == SPSAMD_REPLACE) acc = kv[t];
+	}
+	uint32_t o = hpos[j];
+	row[o] = (int32_t)(key >> minor_bits);
+	col[o] = (int32_t)(key & ((uint64_t(1) << minor_bits) - 1));
+	val[o] = acc;
+}
+
+static unsigned grid_for(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+template <class T>
+static const T *to_device(spsamd_ctx *c, const T *p, size_t n, int mem)
+{
+	if (mem == SPSAMD_MEM_DEVICE || n == 0) return p;
+	T *d = c->arena.get<T>(n);
+	SPS_HIP(hipMemcpyAsync(d, p, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+	return d;
+}
+
+void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int duplicate_policy, int zero_nan, ConMat *out)
+{
+	size_t n = X->nnz;
+	if (n >= (size_t(1) << 31))
+		throw Error{SPSAMD_EINVAL, "operand has 2^31 or more tuples (the reference's int positions cap it too, algorithm.hpp:419)"};
+	uint64_t shape[2] = {X->shape0, X->shape1};
+	out->nrow = shape[lead];
+	out->ncol = shape[1 - lead];
+	out->nnz = 0;
+	out->row = out->col = nullptr;
+	out->val = nullptr;
+	if (n == 0) return;
+	if (!X->idx0 || !X->idx1 || !X->val) throw Error{SPSAMD_EINVAL, "operand with nnz > 0 has a null array"};
+	if (shape[0] > (uint64_t(1) << 31) || shape[1] > (uint64_t(1) << 31))
+		throw Error{SPSAMD_EINVAL, "shape exceeds the int32 index range"};
+
+	const int32_t *d0 = to_device(c, X->idx0, n, X->mem);
+	const int32_t *d1 = to_device(c, X->idx1, n, X->mem);
+	const double *dv = to_device(c, X->val, n, X->mem);
+	const int32_t *major = lead == 0 ? d0 : d1;
+	const int32_t *minor = lead == 0 ? d1 : d0;
+
+	uint32_t *flags = c->arena.get<uint32_t>(2);
+	fill_zero(c, flags, 2 * sizeof(uint32_t));
+	k_inspect<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, dv, n, out->nrow, out->ncol, zero_nan, flags);
+	SPS_LAUNCH_CHECK();
+	uint32_t f = read_back(c, flags);
+	if (f & 1u) throw Error{SPSAMD_EINVAL, "Sparse index out of bounds (VectorCooArray::add would reject it, VectorCooArray.hpp:246-262)"};
+
+	// Consolidate<>: a matching sort_order is trusted (algorithm.hpp:360); so is
+	// an operand the inspection found strictly sorted with no zero values.
+	if (X->sort0 == lead || !(f & 2u)) {
+		out->row = const_cast<int32_t *>(major);
+		out->col = const_cast<int32_t *>(minor);
+		out->val = const_cast<double *>(dv);
+		out->nnz = (uint32_t)n;
+		return;
+	}
+
+	int mb = bits_for(out->ncol), Mb = bits_for(out->nrow);
+	uint64_t *keys0 = c->arena.get<uint64_t>(n), *keys1 = c->arena.get<uint64_t>(n);
+	uint32_t *pay0 = c->arena.get<uint32_t>(n), *pay1 = c->arena.get<uint32_t>(n);
+	k_build_keys<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, n, mb, keys0);
+	SPS_LAUNCH_CHECK();
+	int where = radix_sort_pairs(c, keys0, pay0, keys1, pay1, n, mb + Mb);
+	uint64_t *ks = where ? keys1 : keys0;
+	uint32_t *ps = where ? pay1 : pay0;
+	uint64_t *kk = where ? keys0 : keys1;      // the other key buffer is free now
+
+	double *sval = c->arena.get<double>(n);
+	uint8_t *keep = c->arena.get<uint8_t>(n);
+	uint32_t *first = flags + 1;
+	fill_u32(c, first, 0xFFFFFFFFu, 1);
+	k_gather_flag<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(dv, ps, n, zero_nan, sval, keep, first);
+	SPS_LAUNCH_CHECK();
+	if (zero_nan) {
+		k_apply_first<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(keep, n, first);
+		SPS_LAUNCH_CHECK();
+	}
+	uint32_t *pos = c->arena.get<uint32_t>(n + 1);
+	scan_exclusive_u8_u32(c, keep, pos, n);
+	double *kv = c->arena.get<double>(n);
+	k_compact<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(ks, sval, keep, pos, n, kk, kv);
+	SPS_LAUNCH_CHECK();
+	uint8_t *head = keep;                      // reuse
+	k_heads<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(kk, pos + n, n, head);
+	SPS_LAUNCH_CHECK();
+	uint32_t *hpos = c->arena.get<uint32_t>(n + 1);
+	scan_exclusive_u8_u32(c, head, hpos, n);
+	out->row = c->arena.get<int32_t>(n);
+	out->col = c->arena.get<int32_t>(n);
+	out->val = c->arena.get<double>(n);
+	k_merge<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(kk, kv, head, hpos, pos + n, n, mb, duplicate_policy,
+		out->row, out->col, out->val);
+	SPS_LAUNCH_CHECK();
+	out->nnz = read_back(c, hpos + n);
+}
+
+// ------------------------------------------------------------------ dim_beginnings
+
+__global__ void k_row_flags(const int32_t *row, size_t n, uint8_t *flag)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || row[i] != row[i - 1]) ? 1 : 0;
+}
+
+__global__ void k_row_starts(const int32_t *row, const uint8_t *flag, const uint32_t *pos, size_t n, uint32_t *beg, int32_t *id)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (flag[i]) {
+		beg[pos[i]] = (uint32_t)i;
+		id[pos[i]] = row[i];
+	}
+	if (i == n - 1) beg[pos[n]] = (uint32_t)n;      // sentinel (algorithm.hpp:95-99)
+}
+
+void dim_beginnings(spsamd_ctx *c, const ConMat &m, RowList *out)
+{
+	size_t n = m.nnz;
+	out->nrows = 0;
+	out->beg = c->arena.get<uint32_t>(n + 1);
+	out->id = c->arena.get<int32_t>(n ? n : 1);
+	if (n == 0) return;
+	uint8_t *flag = c->arena.get<uint8_t>(n);
+	uint32_t *pos = c->arena.get<uint32_t>(n + 1);
+	k_row_flags<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(m.row, n, flag);
+	SPS_LAUNCH_CHECK();
+	scan_exclusive_u8_u32(c, flag, pos, n);
+	k_row_starts<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(m.row, flag, pos, n, out->beg, out->id);
+	SPS_LAUNCH_CHECK();
+	out->nrows = read_back(c, pos + n);
+}
+
+// ------------------------------------------------------------------ dense row pointer
+
+__global__ void k_rowptr(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t *ptr)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nptr) return;
+	// first tuple whose row index is >= r
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		uint32_t mid = lo + ((hi - lo) >> 1);
+		if ((uint64_t)(uint32_t)row[mid] < r) lo = mid + 1; else hi = mid;
+	}
+	ptr[r] = lo;
+}
+
+uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra)
+{
+	uint64_t nptr = m.nrow + 1 + extra;
+	uint32_t *ptr = c->arena.get<uint32_t>(nptr);
+	k_rowptr<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+	SPS_LAUNCH_CHECK();
+	return ptr;
+}
+
+// ------------------------------------------------------------------ scale vectors
+
+__global__ void k_scale_scatter(const int32_t *idx, size_t n, uint64_t dim, int32_t *pos, uint32_t *bad)
+{
+	size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	int32_t i = idx[t];
+	if (t > 0 && idx[t - 1] >= i) atomicOr(bad, 1u);
+	// an index outside the dimension can never match in the reference's join
+	if (i >= 0 && (uint64_t)i < dim) pos[i] = (int32_t)t;
+}
+
+void upload_scale(spsamd_ctx *c, const spsamd_vec *s, uint64_t dim, const char *name, ScaleDev *out)
+{
+	out->present = false;
+	if (!s) return;
+	out->present = true;
+	out->dim = dim;
+	size_t n = s->nnz;
+	const int32_t *di = to_device(c, s->idx, n, s->mem);
+	out->val = to_device(c, s->val, n, s->mem);
+	out->pos = c->arena.get<int32_t>(dim ? dim : 1);
+	fill_u32(c, (uint32_t *)out->pos, 0xFFFFFFFFu, dim);
+	if (n == 0) return;
+	uint32_t *bad = c->arena.get<uint32_t>(1);
+	fill_zero(c, bad, sizeof(uint32_t));
+	k_scale_scatter<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(di, n, dim, out->pos, bad);
+	SPS_LAUNCH_CHECK();
+	if (read_back(c, bad))
+		throw Error{SPSAMD_EINVAL, std::string("scale vector ") + name + " is not strictly ascending in its index "
+			"(the reference joins scale vectors as stored and would silently mis-compute, multiply_sparse.hpp:83-85)"};
+}
+
+} // namespace spsamd

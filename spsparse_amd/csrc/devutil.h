@@ -1,0 +1,68 @@
+// devutil.h -- wave64 / workgroup helpers shared by the kernels (gfx950: wavefront = 64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spsamd {
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Inclusive scan across the 64 lanes of a wave.
+template <class T>
+__device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		T o = __shfl_up(v, d, 64);
+		if ((int)lane_id() >= d) v += o;
+	}
+	return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_reduce_sum(T v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+
+// Exclusive scan across a workgroup of NT threads (NT multiple of 64, <= 1024).
+// scratch: NT/64 + 1 entries of T in LDS.  Returns the exclusive prefix of v;
+// *total (if non-null) receives the workgroup sum.  Contains three barriers.
+template <class T, int NT>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *scratch, T *total)
+{
+	constexpr int NW = NT / 64;
+	T inc = wave_inclusive_scan(v);
+	if (lane_id() == 63) scratch[wave_id()] = inc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		T run = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) { T t = scratch[w]; scratch[w] = run; run += t; }
+		scratch[NW] = run;
+	}
+	__syncthreads();
+	T base = scratch[wave_id()];
+	T tot = scratch[NW];
+	__syncthreads();            // scratch may be reused right away
+	if (total) *total = tot;
+	return base + inc - v;
+}
+
+// splitmix64 finaliser applied to (i, j): the index hash of the digest sink.
+// Same arithmetic as orc_mix64 in the test oracle.
+__host__ __device__ __forceinline__ uint64_t mix64(uint32_t i, uint32_t j)
+{
+	uint64_t x = ((uint64_t)i << 32) | (uint64_t)j;
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+
+} // namespace spsamd

@@ -1,0 +1,148 @@
+// internal.h -- shared declarations of the spsparse_amd HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/spsparse_amd.h"
+
+namespace spsamd {
+
+// ---------------------------------------------------------------- errors
+
+struct Error {
+	int code;
+	std::string msg;
+};
+
+#define SPS_HIP(call)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (call);                                                    \
+		if (e_ != hipSuccess)                                                      \
+			throw ::spsamd::Error{SPSAMD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)}; \
+	} while (0)
+
+#define SPS_LAUNCH_CHECK() SPS_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- workspace
+
+// Bump allocator over device slabs.  A multiply carves everything it needs
+// from here; if the first slab was too small extra slabs are chained and the
+// arena is re-made as one slab of the high-water size at the next reset, so a
+// steady-state call does no hipMalloc.
+struct Arena {
+	struct Slab { char *p; size_t cap; size_t used; };
+	std::vector<Slab> slabs;
+	size_t high_water = 0;
+	size_t call_used = 0;
+
+	void *alloc(size_t bytes);
+	void reset();          // start of a call
+	void release();        // free everything
+	void reserve(size_t bytes);
+	template <class T> T *get(size_t n) { return (T *)alloc(n * sizeof(T)); }
+};
+
+// Grow-only device buffer (the context's output buffer, host staging).
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	void ensure(size_t bytes);
+	void release();
+};
+
+} // namespace spsamd
+
+struct spsamd_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	spsamd::Arena arena;
+	spsamd::DevBuf out_i, out_j, out_v;      // SINK_COO result
+	spsamd::DevBuf rowstat_n, rowstat_s;     // DIGEST row statistics
+	void *pinned = nullptr;                  // host staging for small readbacks / fetch
+	size_t pinned_cap = 0;
+	std::string last_error;
+	hipEvent_t ev[8] = {};
+	int num_cu = 256;
+	void *host_staging(size_t bytes);
+};
+
+namespace spsamd {
+
+// ---------------------------------------------------------------- primitives (prims.hip)
+
+// out[i] = sum_{j<i} in[j], out[n] = total (out has n+1 entries).
+void scan_exclusive_u32_i64(spsamd_ctx *c, const uint32_t *in, int64_t *out, size_t n);
+void scan_exclusive_u32_u32(spsamd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
+void scan_exclusive_u8_u32(spsamd_ctx *c, const uint8_t *in, uint32_t *out, size_t n);
+
+// Stable LSD radix sort of (key, payload) pairs on key bits [0, key_bits).
+// Returns which of the two buffer pairs holds the result (0: keys0/pay0, 1: keys1/pay1).
+int radix_sort_pairs(spsamd_ctx *c, uint64_t *keys0, uint32_t *pay0, uint64_t *keys1, uint32_t *pay1,
+	size_t n, int key_bits);
+
+void fill_u32(spsamd_ctx *c, uint32_t *p, uint32_t v, size_t n);
+void fill_zero(spsamd_ctx *c, void *p, size_t bytes);
+
+template <class T>
+T read_back(spsamd_ctx *c, const T *dev)
+{
+	T *h = (T *)c->host_staging(sizeof(T));
+	SPS_HIP(hipMemcpyAsync(h, dev, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+	SPS_HIP(hipStreamSynchronize(c->stream));
+	return *h;
+}
+
+// ---------------------------------------------------------------- consolidated operand (consolidate.hip)
+
+// op(X) in row-major consolidated form on the device.
+struct ConMat {
+	int32_t *row = nullptr;     // leading (row of op(X)) index per tuple
+	int32_t *col = nullptr;     // minor index per tuple
+	double *val = nullptr;
+	uint32_t nnz = 0;
+	uint64_t nrow = 0, ncol = 0;
+};
+
+// Upload (if host) + consolidate `X` by sort order {lead, 1-lead} into `out`
+// (arena memory).  Mirrors Consolidate<> (algorithm.hpp:353-369): an operand
+// whose sort0 == lead is used as is.
+void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int duplicate_policy,
+	int zero_nan, ConMat *out);
+
+// Row boundaries of a consolidated operand: dim_beginnings (algorithm.hpp:74-118):
+// beg[r] for each non-empty row + sentinel, and the row ids.
+struct RowList {
+	uint32_t *beg = nullptr;    // nrows + 1 entries
+	int32_t *id = nullptr;      // nrows entries
+	uint32_t nrows = 0;
+};
+void dim_beginnings(spsamd_ctx *c, const ConMat &m, RowList *out);
+
+// Dense row pointer over all `nrow + extra` rows (extra trailing empty rows).
+uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra);
+
+// ---------------------------------------------------------------- multiply (spgemm.hip)
+
+struct ScaleDev {
+	bool present = false;
+	int32_t *pos = nullptr;     // dense: position in the vector or -1
+	const double *val = nullptr; // device copy of the values
+	uint64_t dim = 0;
+};
+
+void upload_scale(spsamd_ctx *c, const spsamd_vec *s, uint64_t dim, const char *name, ScaleDev *out);
+
+struct MultiplyArgs {
+	double C;
+	ScaleDev si, sj, sk;
+	ConMat A, B;
+	int sink_kind, sink_flags;
+};
+void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res);
+
+} // namespace spsamd

@@ -1,0 +1,353 @@
+"""Parity of the HIP product path (through the C ABI, include/spsparse_amd.h)
+with the CPU oracle.  GPU only.
+
+Bars: index sets identical; values bit-exact where the device sums in the
+reference's ascending-k order (rows with <= 64 products), within 1e-12
+relative (BASELINE.json north_star) where the LDS accumulators add in
+arrival order.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from spsparse_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from spsparse_amd import capi
+    c = capi.Context()
+    yield c
+    c.close()
+
+
+def _dev(ctx, A, B, **kw):
+    """multiply through the C ABI with host operands; returns (i, j, v, res)."""
+    from spsparse_amd import capi
+    keep = []
+
+    def coo(M):
+        s, k = capi.host_coo(M.idx0, M.idx1, M.val, M.shape, M.sort0)
+        keep.append(k)
+        return s
+
+    def vec(V):
+        if V is None:
+            return None
+        s, k = capi.host_vec(V.idx, V.val, V.shape0)
+        keep.append(k)
+        return s
+
+    res = ctx.multiply(coo(A), coo(B), kw.get("C_", 1.0), vec(kw.get("scalei")), kw.get("tA", "."),
+                       vec(kw.get("scalej")), kw.get("tB", "."), vec(kw.get("scalek")),
+                       kw.get("duplicate_policy", capi.ADD), kw.get("zero_nan", False),
+                       kw.get("sink", capi.SINK_COO), kw.get("flags", 0))
+    if kw.get("sink", capi.SINK_COO) == capi.SINK_COO:
+        i, j, v = ctx.fetch(res)
+        return i, j, v, res
+    return None, None, None, res
+
+
+def _check(got, want, exact=False, scale=None):
+    gi, gj, gv = got[:3]
+    wi, wj, wv = want[:3]
+    assert len(gi) == len(wi), (len(gi), len(wi))
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj)
+    if exact:
+        assert np.array_equal(gv, wv)
+    elif len(wv):
+        denom = np.abs(wv) if scale is None else scale
+        assert np.max(np.abs(gv - wv) / denom) <= REL
+    # ascending (i, j), each at most once
+    if len(gi) > 1:
+        key = gi.astype(np.int64) * (int(gj.max()) + 1) + gj
+        assert np.all(np.diff(key) > 0)
+
+
+def test_known_answer(ctx):
+    """tests/test_multiply_sparse.cpp:45-78 -> {(0,0):128, (1,0):60}"""
+    row = orc.Mat([0, 0, 0, 0, 1], [8, 4, 0, 3, 8], [6., 4., 2., 3., 3.], (2, 10))
+    scale = orc.Vec([0, 4, 8], [2., 4., 4.], 10)
+    col = orc.Mat([0, 3, 8], [0, 0, 0], [2., 3., 5.], (10, 1))
+    eye = orc.Vec(list(range(10)), [1.] * 10, 10)
+    i, j, v, res = _dev(ctx, row, col, scalei=eye, scalej=scale, scalek=eye)
+    assert (res.shape0, res.shape1) == (2, 1)
+    assert i.tolist() == [0, 1] and j.tolist() == [0, 0] and v.tolist() == [128., 60.]
+
+
+def test_random_mm_property(ctx):
+    """tests/test_multiply_sparse.cpp:84-136 through the device path: the 999 seeded 5x5 cases with
+    scalej = eye.  Bit-exact against the oracle (which is itself pinned to the dense triple loop)."""
+    from tests.test_oracle_pins import RANDOM5
+    mm, _ = RANDOM5
+    eye = orc.Vec(list(range(5)), [1.] * 5, 5)
+    total = 0
+    for seed, ((ai, av), (bi, bv)) in mm:
+        A = orc.Mat(ai[0], ai[1], av, (5, 5))
+        B = orc.Mat(bi[0], bi[1], bv, (5, 5))
+        want = orc.multiply(A, B, 1.0, scalej=eye)
+        got = _dev(ctx, A, B, scalej=eye)
+        assert (got[3].shape0, got[3].shape1) == (5, 5)
+        _check(got, want, exact=True)
+        total += len(want[2])
+    assert total > 5000
+
+
+def _rand_mat(rng, shape, nnz, zeros=False, positive=True):
+    i0 = rng.integers(0, shape[0], nnz)
+    i1 = rng.integers(0, shape[1], nnz)
+    v = rng.uniform(0.1, 1, nnz) if positive else rng.uniform(-1, 1, nnz)
+    if zeros:
+        v[rng.integers(0, nnz, max(1, nnz // 10))] = 0.0
+    return orc.Mat(i0, i1, v, shape)
+
+
+def _rand_vec(rng, n, density=0.7):
+    idx = np.flatnonzero(rng.uniform(size=n) < density)
+    if idx.size == 0:
+        idx = np.array([0])
+    v = rng.uniform(0.5, 2, idx.size)
+    if idx.size > 3:
+        v[1] = 0.0
+    return orc.Vec(idx, v, n)
+
+
+@pytest.mark.parametrize("tA", [".", "T"])
+@pytest.mark.parametrize("tB", [".", "T"])
+def test_flags_scales_policies(ctx, tA, tB):
+    """'T' flags x scale vectors x C != 1 x each DuplicatePolicy on <= 60x60 inputs
+    (SURVEY 8c golden-vector class iv; the reference's own tests never vary these)."""
+    rng = np.random.default_rng(42)
+    for trial in range(12):
+        m, k, n = rng.integers(1, 60, 3)
+        A = _rand_mat(rng, (k, m) if tA == "T" else (m, k), int(rng.integers(1, 600)), zeros=True)
+        B = _rand_mat(rng, (n, k) if tB == "T" else (k, n), int(rng.integers(1, 600)), zeros=True)
+        kw = dict(C_=17.0, tA=tA, tB=tB,
+                  scalei=_rand_vec(rng, m) if trial % 2 else None,
+                  scalej=_rand_vec(rng, k) if trial % 3 else None,
+                  scalek=_rand_vec(rng, n) if trial % 4 == 1 else None,
+                  duplicate_policy=[orc.ADD, orc.LEAVE_ALONE, orc.REPLACE][trial % 3])
+        want = orc.multiply(A, B, **kw)
+        got = _dev(ctx, A, B, **kw)
+        assert (got[3].shape0, got[3].shape1) == want[3]
+        _check(got, want)
+
+
+def test_cfg1_1k(ctx):
+    """BASELINE cfg1: 1k x 1k, 10 per row, fp64 (duplicates exercise consolidate-ADD)."""
+    for seed in (1, 2):
+        A = orc.Mat(*wl.random_rows(1000, 10, seed, 0))
+        B = orc.Mat(*wl.random_rows(1000, 10, seed, 8))
+        want = orc.multiply(A, B)
+        got = _dev(ctx, A, B)
+        _check(got, want)
+        assert got[3].products > 90000 and 90000 < got[3].nnz < 100000
+        # digest sink agrees with the oracle's digest of the same product
+        from spsparse_amd import capi
+        _, _, _, d = _dev(ctx, A, B, sink=capi.SINK_DIGEST)
+        cnt, s, h = orc.digest(*want[:3])
+        assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
+
+
+@pytest.mark.parametrize("scale", [8, 11, 13])
+def test_rmat_full_compare(ctx, scale):
+    """R-MAT A*A (cfg2's generator at small scale): all three row classes
+    (light / LDS hash / dense windows) against the row-wise oracle, tuple by tuple."""
+    a = wl.rmat(scale, seed=1)
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    got = _dev(ctx, A, A)
+    _check(got, want)
+    res = got[3]
+    assert res.products == res.products_light + res.products_mid + res.products_heavy
+    if scale >= 11:
+        assert res.rows_heavy > 0 and res.rows_mid > 0 and res.rows_light > 0
+    from spsparse_amd import capi
+    _, _, _, d = _dev(ctx, A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    cnt, s, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
+
+
+def test_poisson_exact(ctx):
+    """cfg3 at N=64: values are small integers, so every summation order is exact;
+    closed forms nnz(A)=5N^2-4N, P=25N^2-36N+8, nnz(C)=13N^2-20N+4."""
+    N = 64
+    a = wl.poisson2d(N)
+    A = orc.Mat(*a, sort0=0)
+    want = orc.multiply(A, A, rowwise=True)
+    got = _dev(ctx, A, A)
+    _check(got, want, exact=True)
+    assert A.nnz == 5 * N * N - 4 * N
+    assert got[3].products == 25 * N * N - 36 * N + 8
+    assert got[3].nnz == 13 * N * N - 20 * N + 4
+    assert set(np.unique(got[2]).tolist()) <= {-8., 1., 2., 18., 19., 20.}
+
+
+def test_galerkin_exact(ctx):
+    """cfg5 at N=16: T = R*A, C = T*R^T ('T' flag, multiply_sparse.hpp:168); closed forms
+    nnz(T)=32nc^3-24nc^2, nnz(C)=7nc^3-6nc^2, C values in {24,-4}."""
+    N, nc = 16, 8
+    A = orc.Mat(*wl.laplace3d(N), sort0=0)
+    R = orc.Mat(*wl.aggregation3d(N), sort0=0)
+    wantT = orc.multiply(R, A, rowwise=True)
+    gotT = _dev(ctx, R, A)
+    _check(gotT, wantT, exact=True)
+    assert gotT[3].nnz == 32 * nc ** 3 - 24 * nc ** 2
+    T = orc.Mat(gotT[0], gotT[1], gotT[2], (nc ** 3, N ** 3))
+    wantC = orc.multiply(T, R, tB="T", rowwise=True)
+    gotC = _dev(ctx, T, R, tB="T")
+    _check(gotC, wantC, exact=True)
+    assert gotC[3].nnz == 7 * nc ** 3 - 6 * nc ** 2
+    assert set(np.unique(gotC[2]).tolist()) == {24., -4.}
+
+
+def test_cancellation_closes_holes(ctx):
+    """Sums that are exactly 0 are dropped (multiply_sparse.hpp:238) in every row class, including
+    where the reserve pass is structural (LDS hash / dense windows) and leaves holes to close."""
+    for ncol, reps in ((300, 1), (3000, 1), (9000, 2)):
+        # row 0 of A = [+1, -1, +1 ...] against B rows that agree on even columns and differ on odd ones
+        k = 2 * reps
+        ai0 = np.zeros(k, np.int32)
+        ai1 = np.arange(k, dtype=np.int32)
+        av = np.where(np.arange(k) % 2 == 0, 1.0, -1.0)
+        cols = np.arange(ncol, dtype=np.int32)
+        bi0 = np.repeat(np.arange(k, dtype=np.int32), ncol)
+        bi1 = np.tile(cols, k)
+        bv = np.ones(k * ncol)
+        odd = (bi1 % 2 == 1) & (bi0 % 2 == 1)
+        bv[odd] = 3.0
+        A = orc.Mat(ai0, ai1, av, (1, k))
+        B = orc.Mat(bi0, bi1, bv, (k, ncol))
+        want = orc.multiply(A, B, rowwise=True)
+        got = _dev(ctx, A, B)
+        _check(got, want, exact=True)
+        assert len(want[2]) == ncol // 2 and np.all(got[1] % 2 == 1)
+
+
+def test_short_circuits_and_errors(ctx):
+    from spsparse_amd import capi
+    A = orc.Mat([0], [1], [2.], (2, 3))
+    B = orc.Mat([1], [0], [4.], (3, 2))
+    E = orc.Mat([], [], [], (3, 2))
+    i, j, v, res = _dev(ctx, A, B)
+    assert v.tolist() == [8.] and (res.shape0, res.shape1) == (2, 2)
+    assert _dev(ctx, A, B, C_=0.0)[3].nnz == 0
+    r = _dev(ctx, A, E)[3]
+    assert r.nnz == 0 and (r.shape0, r.shape1) == (2, 2)          # shape set before the short-circuit (:169)
+    assert _dev(ctx, A, B, scalej=orc.Vec([], [], 3))[3].nnz == 0
+    Z = orc.Mat([0], [1], [0.], (2, 3))                             # only explicit zeros (Appendix A.3)
+    assert _dev(ctx, Z, B)[3].nnz == 0
+    with pytest.raises(capi.SpsamdError, match=r"Inner dimensions for A \(3\) and B \(2\) must match!") as e:
+        _dev(ctx, A, orc.Mat([0], [0], [1.], (2, 2)))
+    assert e.value.code == -1
+    with pytest.raises(capi.SpsamdError, match="not strictly ascending"):
+        _dev(ctx, A, B, scalej=orc.Vec([2, 1], [1., 1.], 3))
+    with pytest.raises(capi.SpsamdError, match="out of bounds"):
+        _dev(ctx, orc.Mat([5], [1], [2.], (2, 3)), B)
+    # the context stays usable after an error
+    assert _dev(ctx, A, B)[2].tolist() == [8.]
+
+
+def test_presorted_operands(ctx):
+    """algorithm.hpp:360: a matching sort_order skips the consolidation."""
+    rng = np.random.default_rng(11)
+    A, B = _rand_mat(rng, (30, 30), 200), _rand_mat(rng, (30, 30), 200)
+    a0, a1, av = orc.consolidate(A.idx0, A.idx1, A.val, 0)
+    b0, b1, bv = orc.consolidate(B.idx0, B.idx1, B.val, 0)
+    As, Bs = orc.Mat(a0, a1, av, (30, 30), sort0=0), orc.Mat(b0, b1, bv, (30, 30), sort0=0)
+    want = orc.multiply(A, B)
+    _check(_dev(ctx, As, Bs), want)
+    _check(_dev(ctx, A, B), want)
+
+
+def test_consolidate_known_answer(ctx):
+    """tests/test_array.cpp:135-168 through spsamd_consolidate"""
+    from spsparse_amd import capi
+    s, keep = capi.host_coo([1, 1, 0, 0, 1], [3, 2, 3, 1, 2], [5., 3., 17., 14., 15.], (2, 4))
+    r = ctx.consolidate(s, 0)
+    i, j, v = ctx.fetch(r)
+    assert i.tolist() == [0, 0, 1, 1] and j.tolist() == [1, 3, 2, 3] and v.tolist() == [14., 17., 18., 5.]
+    r = ctx.consolidate(s, 1)
+    i, j, v = ctx.fetch(r)
+    assert i.tolist() == [0, 1, 0, 1] and j.tolist() == [1, 2, 3, 3] and v.tolist() == [14., 18., 17., 5.]
+    # policies and the zero / NaN quirks against the oracle
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = 2000
+        i0, i1 = rng.integers(0, 40, n), rng.integers(0, 50, n)
+        v = rng.uniform(-1, 1, n)
+        v[rng.integers(0, n, 100)] = 0.0
+        if trial % 2:
+            v[rng.integers(0, n, 50)] = np.nan
+        pol = [orc.ADD, orc.LEAVE_ALONE, orc.REPLACE][trial % 3]
+        for so0 in (0, 1):
+            w0, w1, wv = orc.consolidate(i0, i1, v, so0, pol, bool(trial % 2))
+            s, keep = capi.host_coo(i0, i1, v, (40, 50))
+            r = ctx.consolidate(s, so0, pol, bool(trial % 2))
+            g0, g1, gv = ctx.fetch(r)
+            assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+            assert np.array_equal(gv, wv, equal_nan=True)
+
+
+def test_device_generators_match_numpy(ctx):
+    """csrc/workload.hip == spsparse_amd/workloads.py, tuple for tuple."""
+    import torch
+    dev = torch.device("cuda:0")
+
+    def bufs(n):
+        return (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
+                torch.empty(n, dtype=torch.float64, device=dev))
+
+    def same(t, ref):
+        torch.cuda.synchronize()        # device-wide: also drains the library's own stream
+        return all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(t, ref[:3]))
+
+    t = bufs(16 << 10)
+    ctx.gen_rmat(10, 7, 0, 16 << 10, *[x.data_ptr() for x in t])
+    assert same(t, wl.rmat(10, 7))
+    t = bufs(1000)
+    ctx.gen_rmat(10, 7, 5000, 1000, *[x.data_ptr() for x in t])
+    assert same(t, wl.rmat(10, 7, first_edge=5000, n_edges=1000))
+    t = bufs(5000)
+    ctx.gen_random_rows(500, 10, 3, 8, *[x.data_ptr() for x in t])
+    assert same(t, wl.random_rows(500, 10, 3, 8))
+    for N, gen, ref in ((20, ctx.gen_poisson2d, wl.poisson2d), (8, ctx.gen_laplace3d, wl.laplace3d),
+                        (8, ctx.gen_aggregation3d, wl.aggregation3d)):
+        r = ref(N)
+        t = bufs(len(r[2]))
+        gen(N, *[x.data_ptr() for x in t])
+        assert same(t, r)
+
+
+def test_device_resident_operands_rmat15(ctx):
+    """Device-resident operands (the bench's path): R-MAT scale 15 A*A, digest + row statistics
+    against the row-wise oracle (nnz(C) ~ 6e7: compared through count, index hash and row sums)."""
+    import torch
+    from spsparse_amd import capi
+    scale, seed = 15, 1
+    n, ne = 1 << scale, 16 << scale
+    dev = torch.device("cuda:0")
+    t0 = torch.empty(ne, dtype=torch.int32, device=dev)
+    t1 = torch.empty(ne, dtype=torch.int32, device=dev)
+    tv = torch.empty(ne, dtype=torch.float64, device=dev)
+    ctx.gen_rmat(scale, seed, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+    Ad = capi.device_coo(t0.data_ptr(), t1.data_ptr(), tv.data_ptr(), ne, (n, n))
+    d = ctx.multiply(Ad, Ad, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    A = orc.Mat(*wl.rmat(scale, seed))
+    wi, wj, wv, _ = orc.multiply(A, A, rowwise=True, nthreads=16)
+    cnt, s, h = orc.digest(wi, wj, wv)
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
+    rn = ctx.to_host(d.row_nnz, n, np.int64)
+    rs = ctx.to_host(d.row_sum, n, np.float64)
+    want_n = np.bincount(wi, minlength=n)
+    want_s = np.bincount(wi, weights=wv, minlength=n)
+    assert np.array_equal(rn, want_n)
+    nz = want_s != 0
+    assert np.max(np.abs(rs[nz] - want_s[nz]) / np.abs(want_s[nz])) <= 1e-11
+    # the COO sink on the same operands: sorted, same count
+    r = ctx.multiply(Ad, Ad, sink=capi.SINK_COO)
+    assert r.nnz == cnt
