@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- nnz(C)/s of C = A*A on BASELINE.json's cfg2 (R-MAT scale-20, fp64,
+~16M tuples) on N MI355X GPUs of one node, plus the dominant kernel's roofline
+line and (N=1) the CPU port of the reference algorithm beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the whole synthetic matrix:
+  N = 1   spsamd_multiply(A, A) from the raw, device-resident COO tuples
+          (device consolidate + symbolic + numeric) into the digest sink.
+  N > 1   strong scaling on the same matrix: every rank owns a product-balanced
+          contiguous row block of the raw tuples; a step = consolidate the own
+          block, all-to-allv of the needed B row panels (RCCL), multiply the
+          block against its panel.  C stays row partitioned (no reduction).
+The digest sink (count + value sum + index hash of the emitted tuples) is the
+device analogue of the reference's ScalarAccumulator (accum.hpp:158-167):
+nnz(C) ~ 9.7e9 tuples (155 GB) is never materialised.  Inputs are generated
+in HBM before the timed region; nothing crosses PCIe inside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=20, help="R-MAT scale (cfg2 = 20, cfg4 = 23)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=int, default=14, help="R-MAT scale of the bounded CPU sample")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="with --gpus 1: run the row-block + all-to-allv path on a 1-rank group (rehearsal of the N>1 code)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scale, seed):
+    """The CPU port of the reference algorithm (oracle/spsparse_oracle.c,
+    orc_multiply_mm: sorted rows x sorted columns, leap-frog merge joins --
+    multiply_sparse.hpp:192-246) timed on one host core on a bounded sample of
+    the same workload.  Reported beside the GPU number, never the target."""
+    from oracle import binding as orc
+    from spsparse_amd import workloads as wl
+    A = orc.Mat(*wl.rmat(scale, seed))
+    t = time.time()
+    i, j, v, _ = orc.multiply(A, A)
+    dt = time.time() - t
+    t = time.time()
+    i2, _, _, _ = orc.multiply(A, A, rowwise=True)
+    dt2 = time.time() - t
+    assert len(i) == len(i2)
+    return {"value": len(v) / dt, "unit": "nnz(C)/s", "cores": 1, "kind": "port",
+            "sample": "R-MAT scale-%d A*A (same generator, %d tuples -> nnz(C)=%d) in %.1f s; the reference's "
+                      "inner-product algorithm is Theta(rows*cols): extrapolated to scale-20 it needs days" % (scale, A.nnz, len(v), dt),
+            "rowwise_port_value": len(v) / dt2}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from spsparse_amd import capi
+    from spsparse_amd import dist as sd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.dist_path
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    # one explicit HIP stream for everything: torch tensor ops, RCCL collectives and the
+    # library's kernels stay ordered on it (torch's default stream is the NULL handle,
+    # which the C ABI reads as "create a private stream")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = capi.Context(local_rank, stream.cuda_stream)
+    scale, seed = args.scale, args.seed
+    n, ne = 1 << scale, 16 << scale
+
+    def gen_all():
+        t0 = torch.empty(ne, dtype=torch.int32, device=dev)
+        t1 = torch.empty(ne, dtype=torch.int32, device=dev)
+        tv = torch.empty(ne, dtype=torch.float64, device=dev)
+        ctx.gen_rmat(scale, seed, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+        return t0, t1, tv
+
+    def consolidated(coo):
+        """device consolidate -> torch tensors (row, col, val)"""
+        r = ctx.consolidate(coo, 0)
+        m = int(r.nnz)
+        o0 = torch.empty(m, dtype=torch.int32, device=dev)
+        o1 = torch.empty(m, dtype=torch.int32, device=dev)
+        ov = torch.empty(m, dtype=torch.float64, device=dev)
+        ctx.memcpy(o0.data_ptr(), r.idx0, m * 4)
+        ctx.memcpy(o1.data_ptr(), r.idx1, m * 4)
+        ctx.memcpy(ov.data_ptr(), r.val, m * 8)
+        return o0, o1, ov
+
+    raw0, raw1, rawv = gen_all()
+    torch.cuda.synchronize()
+    if not use_dist:
+        A = capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n))
+
+        def step():
+            return ctx.multiply(A, A, sink=capi.SINK_DIGEST), 0
+    else:
+        # setup (untimed): product-balanced contiguous row blocks, identical on every rank
+        c0, c1, cv = consolidated(capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n)))
+        rowlen = torch.bincount(c0.long(), minlength=n)
+        P = sd.row_products(c0, c1, rowlen, n)
+        bounds = sd.product_balanced_bounds(P, world)
+        del c0, c1, cv, P, rowlen
+        keep = (raw0 >= bounds[rank]) & (raw0 < bounds[rank + 1])
+        blk0, blk1, blkv = raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
+        del raw0, raw1, rawv, keep
+        torch.cuda.empty_cache()
+        nblk = blk0.numel()
+
+        def step():
+            a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), nblk, (n, n)))
+            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds, n)
+            Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
+            Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
+            return ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST), remote
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(args.steps):
+        results.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    res, remote = results[-1]
+    if use_dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        stats = torch.tensor([res.nnz_a, res.products, remote], dtype=torch.int64, device=dev)
+        dist.all_reduce(stats)
+        nnz_a, products, remote_total = [int(x) for x in stats.tolist()]
+        nnz_c, vsum, vhash = sd.reduce_digest(int(res.nnz), float(res.sum), int(res.hash), dev)
+    else:
+        nnz_a, products, remote_total = int(res.nnz_a), int(res.products), 0
+        nnz_c, vsum, vhash = int(res.nnz), float(res.sum), int(res.hash)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        # dominant kernel of rank 0: the dense-window kernel of the heavy rows
+        # (k_heavy), timed with HIP events on the library's stream in every step
+        classes = [("k_heavy", "heavy"), ("k_mid", "mid"), ("k_light", "light")]
+        name, cls = max(classes, key=lambda c: getattr(res, "products_" + c[1]))
+        ms_kernel = sum(getattr(r[0], "ms_" + cls) for r in results) / len(results)
+        alg_bytes = 16 * getattr(res, "tuples_" + cls) + 12 * getattr(res, "products_" + cls)
+        achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+        line = {
+            "metric": "nnz(C)/s for C=A*A SpGEMM",
+            "value": nnz_c * args.steps / elapsed,
+            "unit": "nnz(C)/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
+                            "raw COO tuples resident in HBM, digest sink" % (scale, seed),
+                "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
+                "parallelism": "1 GPU" if world == 1 else "%d row blocks (product balanced) + all-to-allv of B row panels" % world,
+                "remote_panel_tuples": remote_total,
+                "digest": {"sum": vsum, "hash": "%016x" % vhash},
+                "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,
+                "products_per_s": products / (ms_step * 1e-3),
+                "stage_ms_rank0": {"consolidate": res.ms_consolidate, "symbolic": res.ms_symbolic, "numeric": res.ms_numeric,
+                                   "light": res.ms_light, "mid": res.ms_mid, "heavy": res.ms_heavy},
+            },
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_scale, seed)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

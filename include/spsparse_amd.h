@@ -117,6 +117,7 @@ typedef struct {
 	float ms_light, ms_mid, ms_heavy;
 	uint64_t rows_light, rows_mid, rows_heavy;
 	uint64_t products_light, products_mid, products_heavy;
+	uint64_t tuples_light, tuples_mid, tuples_heavy;      /* A tuples in the rows of each class */
 } spsamd_result;
 
 /* ---- context ---- */
@@ -161,9 +162,11 @@ typedef int (*spsamd_chunk_fn)(void *user, const int32_t *i, const int32_t *j,
 int spsamd_result_fetch(spsamd_ctx *ctx, const spsamd_result *result,
 	spsamd_chunk_fn cb, void *user);
 
-/* Copy `bytes` from device memory of this context's device (e.g. result->row_nnz)
- * to host memory, ordered after everything queued on the context's stream. */
-int spsamd_copy_to_host(spsamd_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Copy `bytes` between host and/or device memory of this context's device
+ * (e.g. result->row_nnz to the host, result->idx0 into a caller's device
+ * buffer), ordered after everything queued on the context's stream; returns
+ * when the copy is complete. */
+int spsamd_memcpy(spsamd_ctx *ctx, void *dst, const void *src, size_t bytes);
 
 /*
  * Stand-alone consolidate (algorithm.hpp:251-319) of a COO matrix on the

@@ -48,14 +48,15 @@ class Result(C.Structure):
                 ("ms_consolidate", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float),
                 ("ms_total", C.c_float), ("ms_light", C.c_float), ("ms_mid", C.c_float), ("ms_heavy", C.c_float),
                 ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
-                ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64)]
+                ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64),
+                ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64)]
 
 
 CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_size_t)
 
 # every symbol include/spsparse_amd.h declares
 SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
-           "spsamd_multiply", "spsamd_result_fetch", "spsamd_copy_to_host", "spsamd_consolidate", "spsamd_gen_rmat",
+           "spsamd_multiply", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
 
 _lib = None
@@ -90,7 +91,7 @@ def load():
     L.spsamd_multiply.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Coo), C.c_char, P(Vec),
                                   C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_result_fetch.argtypes = [C.c_void_p, P(Result), CHUNK_FN, C.c_void_p]
-    L.spsamd_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.spsamd_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.spsamd_consolidate.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_gen_rmat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
@@ -184,10 +185,13 @@ class Context:
         return oi, oj, ov
 
     def to_host(self, dev_ptr, count, dtype):
-        """numpy copy of `count` elements of device memory (spsamd_copy_to_host)."""
+        """numpy copy of `count` elements of device memory (spsamd_memcpy)."""
         out = np.empty(count, dtype=dtype)
-        self._check(self.L.spsamd_copy_to_host(self.h, out.ctypes.data, dev_ptr, out.nbytes))
+        self._check(self.L.spsamd_memcpy(self.h, out.ctypes.data, dev_ptr, out.nbytes))
         return out
+
+    def memcpy(self, dst_ptr, src_ptr, nbytes):
+        self._check(self.L.spsamd_memcpy(self.h, dst_ptr, src_ptr, nbytes))
 
     # ---- device generators (outputs: caller-owned device pointers)
     def gen_rmat(self, scale, seed, first_edge, n_edges, p0, p1, pv, edge_factor=16):

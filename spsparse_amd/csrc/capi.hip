@@ -155,13 +155,13 @@ extern "C" int spsamd_result_fetch(spsamd_ctx *c, const spsamd_result *res, spsa
 	)
 }
 
-extern "C" int spsamd_copy_to_host(spsamd_ctx *c, void *dst, const void *src, size_t bytes)
+extern "C" int spsamd_memcpy(spsamd_ctx *c, void *dst, const void *src, size_t bytes)
 {
 	if (!c) return SPSAMD_EINVAL;
 	API_GUARD(c,
 		if (bytes && (!dst || !src)) throw Error{SPSAMD_EINVAL, "null pointer"};
 		SPS_HIP(hipSetDevice(c->device));
-		SPS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+		SPS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
 		SPS_HIP(hipStreamSynchronize(c->stream));
 		return SPSAMD_OK;
 	)

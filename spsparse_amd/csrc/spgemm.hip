@@ -138,7 +138,7 @@ __global__ void k_apply_scalej(const int32_t *acol, const double *aval, uint32_t
 	else { acol2[e] = k; aval2[e] = aval[e] * sval[q]; }
 }
 
-struct BinCounters { unsigned long long rows[NBIN]; unsigned long long prods[NBIN]; };
+struct BinCounters { unsigned long long rows[NBIN]; unsigned long long prods[NBIN]; unsigned long long tuples[NBIN]; };
 
 __device__ __forceinline__ int bin_of(uint32_t P)
 {
@@ -156,33 +156,55 @@ __device__ __forceinline__ int bin_of(uint32_t P)
 // Per non-empty A row: product count and bin.  scalei (multiply_sparse.hpp:195
 // and the Join2 of ScaledMultXiter :79-86): a row absent from the vector, or
 // whose scale is 0, is skipped.
-__global__ void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref,
+__global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref,
 	const int32_t *si_pos, const double *si_val, uint32_t *rprod, uint8_t *rbin, BinCounters *bc)
 {
+	// bin statistics are reduced in LDS first: one global atomic per (workgroup, bin)
+	__shared__ unsigned int s_rows[NBIN];
+	__shared__ unsigned long long s_prods[NBIN];
+	__shared__ unsigned long long s_tuples[NBIN];
+	if (threadIdx.x < NBIN) { s_rows[threadIdx.x] = 0; s_prods[threadIdx.x] = 0; s_tuples[threadIdx.x] = 0; }
+	__syncthreads();
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= nrows) return;
-	uint32_t P = (uint32_t)(pref[beg[r + 1]] - pref[beg[r]]);
-	if (si_pos) {
-		int32_t q = si_pos[id[r]];
-		if (q < 0 || si_val[q] == 0) P = 0;
+	if (r < nrows) {
+		uint32_t P = (uint32_t)(pref[beg[r + 1]] - pref[beg[r]]);
+		if (si_pos) {
+			int32_t q = si_pos[id[r]];
+			if (q < 0 || si_val[q] == 0) P = 0;
+		}
+		int b = bin_of(P);
+		rprod[r] = P;
+		rbin[r] = (uint8_t)b;
+		atomicAdd(&s_rows[b], 1u);
+		atomicAdd(&s_prods[b], (unsigned long long)P);
+		atomicAdd(&s_tuples[b], (unsigned long long)(beg[r + 1] - beg[r]));
 	}
-	int b = bin_of(P);
-	rprod[r] = P;
-	rbin[r] = (uint8_t)b;
-	atomicAdd(&bc->rows[b], 1ull);
-	atomicAdd(&bc->prods[b], (unsigned long long)P);
+	__syncthreads();
+	if (threadIdx.x < NBIN && s_rows[threadIdx.x]) {
+		atomicAdd(&bc->rows[threadIdx.x], (unsigned long long)s_rows[threadIdx.x]);
+		atomicAdd(&bc->prods[threadIdx.x], s_prods[threadIdx.x]);
+		atomicAdd(&bc->tuples[threadIdx.x], s_tuples[threadIdx.x]);
+	}
 }
 
 struct BinOffsets { uint32_t off[NBIN + 1]; };
 
-__global__ void k_bin_scatter(const uint8_t *rbin, uint32_t nrows, BinOffsets bo, uint32_t *cursor, uint32_t *binrows)
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *rbin, uint32_t nrows, BinOffsets bo, uint32_t *cursor, uint32_t *binrows)
 {
+	// a workgroup reserves one range per bin with a single global atomic
+	__shared__ unsigned int s_cnt[NBIN];
+	__shared__ unsigned int s_base[NBIN];
+	if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= nrows) return;
-	int b = rbin[r];
-	if (b == 0) return;
-	uint32_t p = atomicAdd(&cursor[b], 1u);
-	binrows[bo.off[b] + p] = r;
+	int b = r < nrows ? rbin[r] : 0;
+	unsigned int local = 0;
+	if (b) local = atomicAdd(&s_cnt[b], 1u);
+	__syncthreads();
+	if (threadIdx.x < NBIN && threadIdx.x > 0 && s_cnt[threadIdx.x])
+		s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+	__syncthreads();
+	if (b) binrows[bo.off[b] + s_base[b] + local] = r;
 }
 
 // ====================================================================== light rows
@@ -800,6 +822,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->products_light = hbc.prods[1] + hbc.prods[2] + hbc.prods[3] + hbc.prods[4];
 	res->products_mid = hbc.prods[5] + hbc.prods[6] + hbc.prods[7];
 	res->products_heavy = hbc.prods[8];
+	res->tuples_light = hbc.tuples[1] + hbc.tuples[2] + hbc.tuples[3] + hbc.tuples[4];
+	res->tuples_mid = hbc.tuples[5] + hbc.tuples[6] + hbc.tuples[7];
+	res->tuples_heavy = hbc.tuples[8];
 
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val};

@@ -1,0 +1,94 @@
+"""Multi-GPU SpGEMM: A sharded by contiguous row blocks, B's needed row panels
+redistributed with one all-to-allv (torch.distributed: RCCL over xGMI on the
+GPU box, gloo in the CPU tests).  No reduction: C stays row partitioned.
+
+The reference is single threaded and has no counterpart of this module
+(SURVEY.md section 8e).  Output row i of C depends only on row i of op(A) and
+the B rows {k : A(i,k) != 0} (the reference's own loop structure,
+multiply_sparse.hpp:192), so the only exchange step is fetching those B rows.
+
+Everything here is tensor plumbing on whatever device the tensors live on;
+the product itself is spsamd_multiply on each rank's GPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def product_balanced_bounds(row_products, nparts):
+    """Contiguous row-block boundaries [b0=0, b1, ..., bN=n] such that every
+    block holds ~1/nparts of the scalar products (equal-size blocks put 40% of
+    an un-permuted R-MAT's products on shard 0).  row_products: int64 [n]."""
+    n = row_products.numel()
+    pref = torch.cumsum(row_products.to(torch.int64), 0)
+    total = int(pref[-1]) if n else 0
+    targets = torch.tensor([total * p // nparts for p in range(1, nparts)], dtype=torch.int64, device=pref.device)
+    cuts = torch.searchsorted(pref, targets, right=False) + 1 if nparts > 1 else targets
+    cuts = torch.clamp(cuts, 0, n)
+    b = [0] + [int(c) for c in cuts.tolist()] + [n]
+    for q in range(1, len(b)):          # monotone
+        b[q] = max(b[q], b[q - 1])
+    return b
+
+
+def row_products(a_row, a_col, b_rowlen, n_rows):
+    """P_r = sum over tuples (r,k) of A of the length of B row k. int64 [n_rows]."""
+    out = torch.zeros(n_rows, dtype=torch.int64, device=a_row.device)
+    out.index_add_(0, a_row.long(), b_rowlen[a_col.long()].to(torch.int64))
+    return out
+
+
+def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None):
+    """All-to-allv of the B row panels this rank's A block needs.
+
+    a_col           inner indices k of this rank's A block tuples
+    b_row/col/val   this rank's own block of B (rows bounds[rank]..bounds[rank+1]), row-major sorted
+    bounds          row-block boundaries of B over the inner dimension, len world+1
+    Returns (row, col, val) of the received panel: the tuples of every B row
+    this rank needs, sorted row-major (owner blocks arrive in rank order), and
+    the number of tuples received from other ranks.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = b_row.device
+    sizes = [bounds[q + 1] - bounds[q] for q in range(world)]
+    my_lo, my_n = bounds[rank], sizes[rank]
+
+    # 1. which rows of each owner do I need?  one byte per row of the inner dimension
+    need = torch.zeros(n_inner, dtype=torch.uint8, device=dev)
+    need[a_col.long()] = 1
+    their_need = torch.empty(my_n * world, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(their_need, need, output_split_sizes=[my_n] * world, input_split_sizes=sizes, group=group)
+
+    # 2. pack, per requester, the tuples of my rows it asked for
+    local_row = (b_row.long() - my_lo)
+    sel = [torch.nonzero(their_need[p * my_n:(p + 1) * my_n][local_row], as_tuple=False).flatten() for p in range(world)]
+    send_counts = torch.tensor([s.numel() for s in sel], dtype=torch.int64, device=dev)
+    recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    order = torch.cat(sel) if world > 1 else sel[0]
+    s_row, s_col, s_val = b_row[order], b_col[order], b_val[order]
+    in_splits = [int(x) for x in send_counts.tolist()]
+    out_splits = [int(x) for x in recv_counts.tolist()]
+    total = sum(out_splits)
+
+    # 3. the all-to-allv proper: (row, col, val) panels
+    r_row = torch.empty(total, dtype=b_row.dtype, device=dev)
+    r_col = torch.empty(total, dtype=b_col.dtype, device=dev)
+    r_val = torch.empty(total, dtype=b_val.dtype, device=dev)
+    dist.all_to_all_single(r_row, s_row, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    dist.all_to_all_single(r_col, s_col, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    dist.all_to_all_single(r_val, s_val, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    remote = total - out_splits[rank]
+    return r_row, r_col, r_val, remote
+
+
+def reduce_digest(count, digest_sum, digest_hash, device, group=None):
+    """Whole-job digest from the per-rank ones (count and the mod-2^64 index
+    hash add as integers, the value sums as doubles)."""
+    lo, hi = digest_hash & 0xFFFFFFFF, digest_hash >> 32          # 32-bit halves: the int64 sums cannot overflow
+    ints = torch.tensor([count, lo, hi], dtype=torch.int64, device=device)
+    flt = torch.tensor([digest_sum], dtype=torch.float64, device=device)
+    dist.all_reduce(ints, group=group)
+    dist.all_reduce(flt, group=group)
+    h = ((int(ints[2]) << 32) + int(ints[1])) % (1 << 64)
+    return int(ints[0]), float(flt[0]), h

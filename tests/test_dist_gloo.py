@@ -1,0 +1,107 @@
+"""The multi-GPU path's host logic on CPU: world_size 2 over gloo.
+
+Row-block partition + the all-to-allv of needed B row panels
+(spsparse_amd/dist.py); each rank's block product is computed by the ORACLE
+here (no GPU in this container) and the concatenation must equal the oracle's
+product of the whole matrices -- the property the sharding relies on:
+C's rows are independent (multiply_sparse.hpp:192), no reduction.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import binding as orc
+from spsparse_amd import dist as sd
+from spsparse_amd import workloads as wl
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if kind == "rmat":
+            a = wl.rmat(9, seed=3)
+            b = a
+        else:                       # rectangular, B != A: R * A of the Galerkin product
+            a = wl.aggregation3d(8)
+            b = wl.laplace3d(8)
+        n_rows, n_inner = a[3]
+        # setup (untimed in the bench): consolidated operands, product-balanced row blocks
+        a0, a1, av = orc.consolidate(a[0], a[1], a[2], 0)
+        b0, b1, bv = orc.consolidate(b[0], b[1], b[2], 0)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+        b_rowlen = torch.bincount(t(b0).long(), minlength=n_inner)
+        P = sd.row_products(t(a0), t(a1), b_rowlen, n_rows)
+        a_bounds = sd.product_balanced_bounds(P, world)
+        b_bounds = sd.product_balanced_bounds(b_rowlen, world)         # B's own distribution over the inner dim
+        assert a_bounds[0] == 0 and a_bounds[-1] == n_rows and all(x <= y for x, y in zip(a_bounds, a_bounds[1:]))
+        shares = [int(P[a_bounds[q]:a_bounds[q + 1]].sum()) for q in range(world)]
+        assert max(shares) <= 0.75 * int(P.sum()) + int(P.max())          # balanced up to one row
+
+        ma = (a0 >= a_bounds[rank]) & (a0 < a_bounds[rank + 1])
+        mb = (b0 >= b_bounds[rank]) & (b0 < b_bounds[rank + 1])
+        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner)
+
+        # the panel holds exactly the B rows this block needs, row-major sorted
+        needed = np.unique(a1[ma])
+        want_mask = np.isin(b0, needed)
+        assert np.array_equal(r_row.numpy(), b0[want_mask])
+        assert np.array_equal(r_col.numpy(), b1[want_mask]) and np.array_equal(r_val.numpy(), bv[want_mask])
+        assert remote == int(np.sum(want_mask & ~mb))
+
+        A_blk = orc.Mat(a0[ma], a1[ma], av[ma], a[3], sort0=0)
+        B_pan = orc.Mat(r_row.numpy(), r_col.numpy(), r_val.numpy(), b[3], sort0=0)
+        ci, cj, cv, _ = orc.multiply(A_blk, B_pan, rowwise=True)
+        cnt, s, h = orc.digest(ci, cj, cv)
+        tot = sd.reduce_digest(cnt, s, h, torch.device("cpu"))
+        np.savez(os.path.join(out_dir, "part%d.npz" % rank), i=ci, j=cj, v=cv, tot=np.array([tot[0], tot[2]], dtype=np.uint64),
+                 tots=np.array([tot[1]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["rmat", "galerkin"])
+def test_row_block_sharding_world2(tmp_path, kind):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "part%d.npz" % r)) for r in range(world)]
+    if kind == "rmat":
+        a = wl.rmat(9, seed=3)
+        b = a
+    else:
+        a, b = wl.aggregation3d(8), wl.laplace3d(8)
+    wi, wj, wv, _ = orc.multiply(orc.Mat(*a), orc.Mat(*b), rowwise=True)
+    gi = np.concatenate([p["i"] for p in parts])
+    gj = np.concatenate([p["j"] for p in parts])
+    gv = np.concatenate([p["v"] for p in parts])
+    # blocks are contiguous and ordered: plain concatenation is the row-major product
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gv, wv)
+    cnt, s, h = orc.digest(wi, wj, wv)
+    for p in parts:
+        assert int(p["tot"][0]) == cnt and int(p["tot"][1]) == h
+        assert abs(float(p["tots"][0]) - s) <= 1e-12 * abs(s)
+
+
+def test_balanced_bounds_edge_cases():
+    P = torch.tensor([0, 0, 10, 0, 5, 5, 0], dtype=torch.int64)
+    b = sd.product_balanced_bounds(P, 2)
+    assert b[0] == 0 and b[-1] == 7 and int(P[b[0]:b[1]].sum()) == 10
+    b = sd.product_balanced_bounds(P, 4)
+    assert len(b) == 5 and all(x <= y for x, y in zip(b, b[1:]))
+    b = sd.product_balanced_bounds(torch.zeros(5, dtype=torch.int64), 3)
+    assert b[0] == 0 and b[-1] == 5
+    assert sd.product_balanced_bounds(P, 1) == [0, 7]
