@@ -1,0 +1,278 @@
+// spsparse_amd/multiply.hpp -- header-only host shim with the call shape of
+// spsparse::multiply() (slib/spsparse/multiply_sparse.hpp:138-164) on top of
+// the C ABI in spsparse_amd.h.  Migration is
+//     s/spsparse::multiply/spsparse_amd::multiply/
+// Operands may be spsparse::VectorCooArray (the real one) or the mirror type
+// below: the template only touches the members the reference touches
+// (shape, size(), index(d,i), val(i), sort_order -- VectorCooArray.hpp:17,45-53,
+// 85-86,35).  Results stream into any Accumulator with val_type / set_shape /
+// add (accum.hpp:12-24), in ascending (i,j), zeros dropped
+// (multiply_sparse.hpp:238-243).  Errors go through a printf-style hook that
+// defaults to throwing, like spsparse_error (spsparse.hpp:47,54; spsparse.cpp:12-28).
+// Requires C++17 (inline variable for the hook).  No CPU fallback: without a
+// gfx950 device the call raises through the hook.
+#pragma once
+
+#include <array>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <memory>
+#include <sstream>
+#include <type_traits>
+#include <vector>
+
+#include "../spsparse_amd.h"
+
+namespace spsparse_amd {
+
+// ---- spsparse.hpp:25-54 -------------------------------------------------
+enum class DuplicatePolicy { LEAVE_ALONE, ADD, REPLACE };
+
+class Exception : public std::exception {
+public:
+	virtual ~Exception() {}
+	virtual const char *what() const noexcept { return "spsparse_amd::Exception()"; }
+};
+
+typedef void (*error_ptr)(int retcode, char const *str, ...);
+
+inline void default_error(int retcode, const char *format, ...)
+{
+	(void)retcode;
+	va_list arglist;
+	va_start(arglist, format);
+	std::vfprintf(stderr, format, arglist);
+	va_end(arglist);
+	std::fprintf(stderr, "\n");
+	throw Exception();
+}
+
+// User-replaceable, like spsparse::spsparse_error.
+inline error_ptr spsparse_error = &default_error;
+
+// spsparse.cpp:30-31
+inline const std::array<int, 2> ROW_MAJOR = {0, 1};
+inline const std::array<int, 2> COL_MAJOR = {1, 0};
+
+// ---- one device context per host thread (created on first use) ----------
+class Context {
+	spsamd_ctx *c_ = nullptr;
+public:
+	explicit Context(int device = -1, void *hip_stream = nullptr)
+	{
+		int rc = spsamd_ctx_create(&c_, device, hip_stream);
+		if (rc != 0) (*spsparse_error)(-1, "spsparse_amd: cannot create a device context (code %d): no MI355X visible?", rc);
+	}
+	~Context() { if (c_) spsamd_ctx_destroy(c_); }
+	Context(const Context &) = delete;
+	Context &operator=(const Context &) = delete;
+	spsamd_ctx *get() const { return c_; }
+};
+
+inline Context &default_context()
+{
+	static thread_local std::unique_ptr<Context> ctx;
+	if (!ctx) ctx.reset(new Context());
+	return *ctx;
+}
+
+// ---- host container with VectorCooArray's surface (VectorCooArray.hpp:8-158)
+template <class IndexT, class ValT, int RANK>
+class VectorCooArray {
+public:
+	static const int rank = RANK;
+	typedef IndexT index_type;
+	typedef ValT val_type;
+	typedef std::array<index_type, RANK> indices_type;
+
+	std::array<size_t, RANK> shape;
+	bool edit_mode;
+	std::array<int, RANK> sort_order;
+
+	VectorCooArray() : edit_mode(true), sort_order() { sort_order[0] = -1; for (int k = 0; k < RANK; ++k) shape[k] = 0; }
+	explicit VectorCooArray(std::array<size_t, RANK> const &_shape) : shape(_shape), edit_mode(true), sort_order() { sort_order[0] = -1; }
+
+	void set_shape(std::array<size_t, RANK> const &_shape) { shape = _shape; }
+	std::unique_ptr<VectorCooArray> new_blank() const { return std::unique_ptr<VectorCooArray>(new VectorCooArray(shape)); }
+
+	IndexT &index(int dim, size_t ix) { return index_vecs[dim][ix]; }
+	IndexT const &index(int dim, size_t ix) const { return index_vecs[dim][ix]; }
+	ValT &val(size_t ix) { return val_vec[ix]; }
+	ValT const &val(size_t ix) const { return val_vec[ix]; }
+	std::array<IndexT, RANK> index(int ix) const
+	{
+		std::array<IndexT, RANK> r;
+		for (int k = 0; k < RANK; ++k) r[k] = index(k, (size_t)ix);
+		return r;
+	}
+	size_t size() const { return val_vec.size(); }
+	void clear()
+	{
+		for (int k = 0; k < RANK; ++k) index_vecs[k].clear();
+		val_vec.clear();
+		edit_mode = true;
+		sort_order[0] = -1;
+	}
+	void reserve(size_t n) { for (int k = 0; k < RANK; ++k) index_vecs[k].reserve(n); val_vec.reserve(n); }
+	void edit() { edit_mode = true; sort_order[0] = -1; }
+	void set_sorted(std::array<int, RANK> _sort_order) { sort_order = _sort_order; edit_mode = false; }
+
+	// VectorCooArray.hpp:238-266
+	void add(std::array<IndexT, RANK> const index, ValT const val)
+	{
+		if (!edit_mode) (*spsparse_error)(-1, "Must be in edit mode to use VectorCooArray::add()");
+		for (int i = 0; i < RANK; ++i) {
+			if (index[i] < 0 || (size_t)index[i] >= shape[i]) {
+				std::ostringstream buf;
+				buf << "Sparse index out of bounds: index=(";
+				for (int j = 0; j < RANK; ++j) buf << index[j] << " ";
+				buf << ") vs. shape=(";
+				for (int j = 0; j < RANK; ++j) buf << shape[j] << " ";
+				buf << ")";
+				(*spsparse_error)(-1, "%s", buf.str().c_str());
+			}
+		}
+		for (int i = 0; i < RANK; ++i) index_vecs[i].push_back(index[i]);
+		val_vec.push_back(val);
+	}
+
+	// In-place device consolidate (VectorCooArray.hpp:299-311), rank 2 only.
+	void consolidate(std::array<int, RANK> const &_sort_order, DuplicatePolicy duplicate_policy = DuplicatePolicy::ADD,
+		bool handle_nan = false);
+
+protected:
+	std::array<std::vector<IndexT>, RANK> index_vecs;
+	std::vector<ValT> val_vec;
+};
+
+template <class IndexT, class ValT>
+using VectorCooMatrix = VectorCooArray<IndexT, ValT, 2>;
+template <class IndexT, class ValT>
+using VectorCooVector = VectorCooArray<IndexT, ValT, 1>;
+
+namespace detail {
+
+template <class MatT>
+spsamd_coo as_coo(MatT const &A)
+{
+	static_assert(sizeof(typename MatT::index_type) == 4 && std::is_integral<typename MatT::index_type>::value,
+		"spsparse_amd: index_type must be a 32-bit integer");
+	static_assert(std::is_same<typename MatT::val_type, double>::value, "spsparse_amd: val_type must be double");
+	static_assert(MatT::rank == 2, "matrix operand must have rank 2");
+	spsamd_coo c;
+	size_t n = A.size();
+	c.idx0 = n ? reinterpret_cast<const int32_t *>(&A.index(0, 0)) : nullptr;
+	c.idx1 = n ? reinterpret_cast<const int32_t *>(&A.index(1, 0)) : nullptr;
+	c.val = n ? &A.val(0) : nullptr;
+	c.nnz = n;
+	c.shape0 = A.shape[0];
+	c.shape1 = A.shape[1];
+	// the reference compares the whole sort_order (algorithm.hpp:360); for rank 2 the first entry decides
+	c.sort0 = (A.sort_order[0] == 0 && A.sort_order[1] == 1) ? 0 : ((A.sort_order[0] == 1 && A.sort_order[1] == 0) ? 1 : -1);
+	c.mem = SPSAMD_MEM_HOST;
+	return c;
+}
+
+template <class VecT>
+spsamd_vec as_vec(VecT const &V)
+{
+	static_assert(VecT::rank == 1, "scale operand must have rank 1");
+	spsamd_vec v;
+	size_t n = V.size();
+	v.idx = n ? reinterpret_cast<const int32_t *>(&V.index(0, 0)) : nullptr;
+	v.val = n ? &V.val(0) : nullptr;
+	v.nnz = n;
+	v.shape0 = V.shape[0];
+	v.sort0 = V.sort_order[0];
+	v.mem = SPSAMD_MEM_HOST;
+	return v;
+}
+
+template <class AccumulatorT>
+int add_chunk(void *user, const int32_t *i, const int32_t *j, const double *v, size_t n)
+{
+	AccumulatorT &ret = *static_cast<AccumulatorT *>(user);
+	for (size_t q = 0; q < n; ++q) ret.add({i[q], j[q]}, v[q]);      // multiply_sparse.hpp:242
+	return 0;
+}
+
+} // namespace detail
+
+// ---- multiply, matrix x matrix: multiply_sparse.hpp:152-248 ---------------
+template <class ScaleIT, class MatAT, class ScaleJT, class MatBT, class ScaleKT, class AccumulatorT>
+void multiply(
+	AccumulatorT &ret,
+	double C,                // Multiply everything by this
+	ScaleIT const *scalei,
+	MatAT const &A,
+	char transpose_A,        // 'T' for transpose, '.' otherwise
+	ScaleJT const *scalej,
+	MatBT const &B,
+	char transpose_B,        // 'T' for transpose, '.' otherwise
+	ScaleKT const *scalek,
+	DuplicatePolicy duplicate_policy = DuplicatePolicy::ADD,
+	bool zero_nan = false)
+{
+	// Set dimensions of output, even if we store nothing in it (multiply_sparse.hpp:166-169)
+	std::array<int, 2> const &a_sort_order(transpose_A == 'T' ? COL_MAJOR : ROW_MAJOR);
+	std::array<int, 2> const &b_sort_order(transpose_B == 'T' ? ROW_MAJOR : COL_MAJOR);
+	ret.set_shape({A.shape[a_sort_order[0]], B.shape[b_sort_order[0]]});
+
+	// Check inner dimensions (:172-174)
+	if (A.shape[a_sort_order[1]] != B.shape[b_sort_order[1]]) {
+		(*spsparse_error)(-1, "Inner dimensions for A (%ld) and B (%ld) must match!",
+			(long)A.shape[a_sort_order[1]], (long)B.shape[b_sort_order[1]]);
+		return;              // a user handler may return
+	}
+
+	// Short-circuit return on empty output (:178-184)
+	if ((C == 0)
+		|| (scalei && scalei->size() == 0)
+		|| (A.size() == 0)
+		|| (scalej && scalej->size() == 0)
+		|| (B.size() == 0)
+		|| (scalek && scalek->size() == 0))
+	{ return; }
+
+	spsamd_coo a = detail::as_coo(A), b = detail::as_coo(B);
+	spsamd_vec si, sj, sk;
+	if (scalei) si = detail::as_vec(*scalei);
+	if (scalej) sj = detail::as_vec(*scalej);
+	if (scalek) sk = detail::as_vec(*scalek);
+
+	spsamd_ctx *ctx = default_context().get();
+	if (!ctx) return;
+	spsamd_result res;
+	int rc = spsamd_multiply(ctx, C, scalei ? &si : nullptr, &a, transpose_A, scalej ? &sj : nullptr, &b, transpose_B,
+		scalek ? &sk : nullptr, (int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, 0, &res);
+	if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
+	rc = spsamd_result_fetch(ctx, &res, &detail::add_chunk<AccumulatorT>, &ret);
+	if (rc != 0) (*spsparse_error)(-1, "%s", spsamd_last_error(ctx));
+}
+
+// ---- VectorCooArray::consolidate on the device ---------------------------
+template <class IndexT, class ValT, int RANK>
+void VectorCooArray<IndexT, ValT, RANK>::consolidate(std::array<int, RANK> const &_sort_order,
+	DuplicatePolicy duplicate_policy, bool handle_nan)
+{
+	static_assert(RANK == 2, "device consolidate is implemented for matrices");
+	if (this->sort_order == _sort_order && !edit_mode) return;       // VectorCooArray.hpp:306
+	VectorCooArray ret(shape);
+	if (size() > 0) {
+		spsamd_coo a = detail::as_coo(*this);
+		a.sort0 = -1;
+		spsamd_ctx *ctx = default_context().get();
+		spsamd_result res;
+		int rc = spsamd_consolidate(ctx, &a, _sort_order[0], (int)duplicate_policy, handle_nan ? 1 : 0, &res);
+		if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
+		ret.reserve((size_t)res.nnz);
+		rc = spsamd_result_fetch(ctx, &res, &detail::add_chunk<VectorCooArray>, &ret);
+		if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
+	}
+	ret.set_sorted(_sort_order);
+	*this = std::move(ret);
+}
+
+} // namespace spsparse_amd
