@@ -115,6 +115,10 @@ typedef struct {
 	/* numeric kernels by row class (P_r = products of the output row):
 	 * light P_r <= 64, mid <= 4096, heavy above */
 	float ms_light, ms_mid, ms_heavy;
+	float ms_dense;               /* part of ms_heavy spent in the dense-window kernel */
+	uint32_t pad_;
+	uint64_t cells_hash, cells_dense;   /* heavy rows are cut into cells: LDS-hash cells and dense-window cells */
+	uint64_t products_dense;            /* products of the dense-window cells (part of products_heavy) */
 	uint64_t rows_light, rows_mid, rows_heavy;
 	uint64_t products_light, products_mid, products_heavy;
 	uint64_t tuples_light, tuples_mid, tuples_heavy;      /* A tuples in the rows of each class */

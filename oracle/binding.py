@@ -219,10 +219,8 @@ def mix64(i, j):
     """Vectorised orc_mix64 (numpy uint64, wraps mod 2^64)."""
     x = (np.asarray(i).astype(np.uint64) << np.uint64(32)) | np.asarray(j).astype(np.uint64)
     with np.errstate(over="ignore"):
-        x = x + np.uint64(0x9E3779B97F4A7C15)
-        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    return x ^ (x >> np.uint64(31))
+        x = x * np.uint64(0x9E3779B97F4A7C15)
+    return x ^ (x >> np.uint64(29))
 
 
 def digest(i, j, v):

@@ -652,11 +652,8 @@ done:
 
 uint64_t orc_mix64(uint32_t i, uint32_t j)
 {
-	uint64_t x = ((uint64_t)i << 32) | (uint64_t)j;
-	x += 0x9E3779B97F4A7C15ull;
-	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-	return x ^ (x >> 31);
+	uint64_t x = ((((uint64_t)i) << 32) | (uint64_t)j) * 0x9E3779B97F4A7C15ull;
+	return x ^ (x >> 29);
 }
 
 void orc_digest(const orc_coo *c, uint64_t *count, double *sum, uint64_t *hash)

@@ -54,15 +54,12 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch, T *total)
 	return base + inc - v;
 }
 
-// splitmix64 finaliser applied to (i, j): the index hash of the digest sink.
+// Index hash of the digest sink: one 64-bit multiply and a fold of (i, j).
 // Same arithmetic as orc_mix64 in the test oracle.
 __host__ __device__ __forceinline__ uint64_t mix64(uint32_t i, uint32_t j)
 {
-	uint64_t x = ((uint64_t)i << 32) | (uint64_t)j;
-	x += 0x9E3779B97F4A7C15ull;
-	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-	return x ^ (x >> 31);
+	uint64_t x = (((uint64_t)i << 32) | (uint64_t)j) * 0x9E3779B97F4A7C15ull;
+	return x ^ (x >> 29);
 }
 
 } // namespace spsamd

@@ -66,7 +66,7 @@ struct spsamd_ctx {
 	void *pinned = nullptr;                  // host staging for small readbacks / fetch
 	size_t pinned_cap = 0;
 	std::string last_error;
-	hipEvent_t ev[8] = {};
+	hipEvent_t ev[10] = {};
 	int num_cu = 256;
 	void *host_staging(size_t bytes);
 };

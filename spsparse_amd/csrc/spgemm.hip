@@ -26,6 +26,7 @@
 #include "devutil.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace spsamd {
 
@@ -325,140 +326,322 @@ __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t
 	}
 }
 
-// ====================================================================== mid rows (LDS hash)
+// ====================================================================== hash cells (LDS hash accumulator)
 
-template <int NT>
-__device__ __forceinline__ uint32_t find_entry(const uint32_t *epref, uint32_t p)
+// A cell is the unit of numeric work above the light bin: one output row
+// restricted to a range [wa, wb) of column windows.
+//   mid rows   (P_r <= 4096): one cell = the whole row (no window index needed)
+//   heavy rows (P_r >  4096): consecutive windows are grouped greedily into
+//       hash cells of <= 4096 products; a single window holding more than that
+//       becomes a dense cell (k_dense).
+// A cell is one output segment of the COO sink (cells of a row in window order).
+struct Cell {
+	uint32_t beg, end; // the row's A tuples
+	int32_t rowid;     // row index of op(A)
+	uint32_t seg;      // output segment id (COO sink)
+	uint32_t prods;    // scalar products in the cell
+	uint16_t wa, wb;   // window range
+	uint32_t pad[2];
+};
+
+// Flattened product loop.  A chunk of NT A-tuples selects NT B segments
+// (start, length); the scalar products of the chunk are numbered 0..total-1
+// and dealt to the threads 64 consecutive products per wave, so consecutive
+// lanes read consecutive B tuples of a segment (coalesced).  Finding the
+// segment of product p costs no search: the segments with length > 0 are
+// compacted, every such segment sets one bit (its first product) in a 64-bit
+// mask per 64-product block, and lane j takes
+//     q = bq[block] + popcount(mask[block] & bits(1..j))
+// where bq[block] is the segment of the block's first product.
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does
+// not drain the wave's outstanding global loads (vmcnt), so prefetched operands
+// stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT, int PB>
+struct Expand {
+	uint32_t cpref[NT + 1];          // compacted segments: exclusive product prefix (+ total)
+	uint32_t cstart[NT];             // first B tuple of the segment
+	double caval[NT];                // the A value
+	unsigned long long bmask[PB / 64];
+	uint32_t bq[PB / 64];
+	uint32_t scrL[2][NT / 64], scrN[2][NT / 64];    // per-wave totals, double buffered
+};
+
+// Segment (lo, len, a) of this thread's A tuple -> compacted arrays.  Returns
+// the product total of the chunk and the number of non-empty segments.  One
+// barrier inside; the arrays become visible at expand_batch's first barrier.
+template <int NT, int PB>
+__device__ __forceinline__ void expand_load(Expand<NT, PB> &L, uint32_t lo, uint32_t len, double a, uint32_t *total, uint32_t *nzc,
+	uint32_t &flip)
 {
-	// largest q in [0, NT) with epref[q] <= p   (epref ascending, epref[0] = 0)
-	uint32_t lo = 0, hi = NT;
-	while (hi - lo > 1) {
-		uint32_t mid = (lo + hi) >> 1;
-		if (epref[mid] <= p) lo = mid; else hi = mid;
+	constexpr int NW = NT / 64;
+	const uint32_t inc = wave_inclusive_scan(len);
+	const uint64_t nzm = __ballot(len != 0);
+	const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
+	if (lane_id() == 63) L.scrL[flip][wave_id()] = inc;
+	if (lane_id() == 0) L.scrN[flip][wave_id()] = (uint32_t)__popcll(nzm);
+	lds_barrier();
+	uint32_t baseL = 0, baseN = 0, totL = 0, totN = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		uint32_t l = L.scrL[flip][w], n = L.scrN[flip][w];
+		if (w < (int)wave_id()) { baseL += l; baseN += n; }
+		totL += l; totN += n;
 	}
-	return lo;
+	flip ^= 1u;
+	if (len) {
+		uint32_t rank = baseN + wrank;
+		L.cpref[rank] = baseL + inc - len;
+		L.cstart[rank] = lo;
+		L.caval[rank] = a;
+	}
+	if (threadIdx.x == 0) L.cpref[totN] = totL;
+	*total = totL;
+	*nzc = totN;
 }
 
-// One workgroup per row; T hash slots (T/2 = the bin's product cap).
-template <int T, int MODE>
-__global__ __launch_bounds__(256) void k_mid(const uint32_t *binrows, uint32_t nbin, RowMeta m, EmitParams ep, SinkParams sk)
+// Prepare the lookup tables for products [pb, pe), pe - pb <= PB.  Two barriers.
+template <int NT, int PB>
+__device__ __forceinline__ void expand_batch(Expand<NT, PB> &L, uint32_t pb, uint32_t pe, uint32_t nzc)
 {
-	constexpr int NT = 256;
+	const uint32_t nblk = (pe - pb + 63) >> 6;
+	for (uint32_t b = threadIdx.x; b < nblk; b += NT) L.bmask[b] = 0;
+	lds_barrier();
+	for (uint32_t b = threadIdx.x; b < nblk; b += NT) {
+		// segment holding the block's first product: largest q with cpref[q] <= p
+		uint32_t p = pb + (b << 6), lo = 0, hi = nzc - 1;
+		while (hi > lo) {
+			uint32_t mid = (lo + hi + 1) >> 1;
+			if (L.cpref[mid] <= p) lo = mid; else hi = mid - 1;
+		}
+		L.bq[b] = lo;
+	}
+	for (uint32_t i = threadIdx.x; i < nzc; i += NT) {
+		uint32_t s = L.cpref[i];
+		if (s > pb && s < pe && ((s - pb) & 63u)) atomicOr(&L.bmask[(s - pb) >> 6], 1ull << ((s - pb) & 63u));
+	}
+	lds_barrier();
+}
+
+template <int NT, int PB>
+__device__ __forceinline__ uint32_t expand_lookup(const Expand<NT, PB> &L, uint32_t p, uint32_t pb)
+{
+	const uint32_t b = (p - pb) >> 6, j = (p - pb) & 63u;
+	return L.bq[b] + (uint32_t)__popcll(L.bmask[b] & ((2ull << j) - 1ull));
+}
+
+// Cells for the mid rows (P_r <= 4096): the whole row, no window index.
+__global__ void k_row_cells(const uint32_t *binrows, uint32_t n, const uint32_t *rbeg, const int32_t *rid, const uint32_t *rprod,
+	const uint32_t *segbase, Cell *cells)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t r = binrows[i];
+	Cell c;
+	c.beg = rbeg[r]; c.end = rbeg[r + 1]; c.rowid = rid[r]; c.seg = segbase ? segbase[r] : 0; c.prods = rprod[r];
+	c.wa = c.wb = 0; c.pad[0] = c.pad[1] = 0;
+	cells[i] = c;
+}
+
+// Persistent workgroups walk the cell list with a grid stride (the list is in
+// window-major order, so concurrently processed cells read the same column
+// windows of B).  T hash slots (T/2 = the product cap of the class); the table
+// is cleaned as it is emitted (list of occupied slots), so a cell costs work
+// proportional to its products, not to T.
+template <int T, int NT, int MODE, bool WINDOWED>
+__global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, RowMeta m,
+	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
+{
 	constexpr int LOGT = T == 1024 ? 10 : (T == 4096 ? 12 : 13);
 	__shared__ int32_t h_key[T];
 	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
+	__shared__ uint16_t occ[T / 2];
 	__shared__ uint64_t s_sort[MODE == MODE_STORE ? T / 2 : 1];
-	__shared__ uint32_t epref[NT + 1];
-	__shared__ uint32_t estart[NT];
-	__shared__ double eaval[NT];
+	__shared__ Expand<NT, T / 2> X;
 	__shared__ uint32_t scr32[NT / 64 + 1];
-	__shared__ unsigned long long s_u64[8];
-	__shared__ double s_f64[4];
+	__shared__ uint32_t s_nocc;
+	__shared__ unsigned long long s_u64[2 * (NT / 64)];
+	__shared__ double s_f64[NT / 64];
 
-	const uint32_t r = binrows[blockIdx.x];
-	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
-	const int32_t rowid = m.id[r];
 	const unsigned tid = threadIdx.x;
-
 	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
-	__syncthreads();
+	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
+	uint32_t flip = 0;
 
-	for (uint32_t chunk = beg; chunk < end; chunk += NT) {
-		uint32_t e = chunk + tid;
-		uint32_t lo = 0, len = 0; double a = 0;
-		if (e < end) { int32_t k = m.acol[e]; lo = m.bptr[k]; len = m.bptr[k + 1] - lo; a = m.aval[e]; }
-		uint32_t total;
-		uint32_t ex = block_exclusive_scan<uint32_t, NT>(len, scr32, &total);
-		epref[tid] = ex; estart[tid] = lo; eaval[tid] = a;
-		if (tid == 0) epref[NT] = total;
-		__syncthreads();
-		for (uint32_t p = tid; p < total; p += NT) {
-			uint32_t q = find_entry<NT>(epref, p);
-			uint32_t bp = estart[q] + (p - epref[q]);
-			int32_t col = m.bcol[bp];
-			uint32_t h = ((uint32_t)col * 0x9E3779B1u) >> (32 - LOGT);
-			for (;;) {
-				int32_t old = atomicCAS(&h_key[h], -1, col);
-				if (old == -1 || old == col) break;
-				h = (h + 1) & (T - 1);
-			}
-			if (MODE != MODE_COUNT) atomicAdd(&h_val[h], eaval[q] * m.bval[bp]);
+	// Software pipeline over the cells of this workgroup: the record of cell i+2, the A tuples of
+	// cell i+1 and then its B segment bounds are loaded while cell i is processed (the barriers
+	// inside are LDS-only, so these loads stay in flight).
+	const uint32_t stride = gridDim.x;
+	Cell rec1{}, rec2{};
+	if (blockIdx.x < ncell) rec1 = cells[blockIdx.x];
+	if (blockIdx.x + stride < ncell) rec2 = cells[blockIdx.x + stride];
+	uint32_t nlo = 0, nlen = 0; double na = 0;
+	{
+		uint32_t e = rec1.beg + tid;
+		if (blockIdx.x < ncell && e < rec1.end) {
+			int32_t k = m.acol[e];
+			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)k * nwin1; nlo = bw[rec1.wa]; nlen = bw[rec1.wb] - nlo; }
+			else { nlo = m.bptr[k]; nlen = m.bptr[k + 1] - nlo; }
+			na = m.aval[e];
 		}
-		__syncthreads();
 	}
+	for (uint32_t ci = blockIdx.x; ci < ncell; ci += stride) {
+		const Cell cell = rec1;
+		const uint32_t beg = cell.beg, end = cell.end, wa = cell.wa, wb = cell.wb, seg = cell.seg;
+		const int32_t rowid = cell.rowid;
+		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
+		// stage A / B of the pipeline
+		rec1 = rec2;
+		if (ci + 2 * stride < ncell) rec2 = cells[ci + 2 * stride];
+		int32_t nk = 0; bool nact = false;
+		if (ci + stride < ncell) {
+			uint32_t e = rec1.beg + tid;
+			nact = e < rec1.end;
+			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
+		}
+		lds_barrier();                                              // previous cell fully emitted, its s_nocc read
+		if (tid == 0) s_nocc = 0;
 
-	const double a_scale = row_scale(ep, rowid);
-	if (MODE == MODE_COUNT) {
-		// structural count (an upper bound when sums cancel to exactly 0)
-		uint32_t c = 0;
-		for (int q = tid; q < T; q += NT) { int32_t col = h_key[q]; if (col >= 0 && col_allowed(ep, col)) ++c; }
-		uint32_t total;
-		block_exclusive_scan<uint32_t, NT>(c, scr32, &total);
-		if (tid == 0) sk.segcount[sk.segbase[r]] = total;
-	} else if (MODE == MODE_DIGEST) {
-		unsigned long long cnt = 0, hash = 0; double vs = 0;
-		for (int q = tid; q < T; q += NT) {
-			int32_t col = h_key[q];
-			double v;
-			if (col >= 0 && emit_value(ep, a_scale, col, h_val[q], &v)) { ++cnt; hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
-		}
-		if (sk.row_nnz) {
-			unsigned long long rc = wave_reduce_sum(cnt); double rs = wave_reduce_sum(vs);
-			if (lane_id() == 0) { s_u64[wave_id()] = rc; s_f64[wave_id()] = rs; }
-			__syncthreads();
-			if (tid == 0) {
-				unsigned long long c = 0; double s = 0;
-				for (int w = 0; w < NT / 64; ++w) { c += s_u64[w]; s += s_f64[w]; }
-				sk.row_nnz[rowid] = (long long)c; sk.row_sum[rowid] = s;
+		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
+			uint32_t lo = lo0, len = len0; double a = a0;
+			if (chunk != beg) {
+				uint32_t e = chunk + tid;
+				lo = 0; len = 0; a = 0;
+				if (e < end) {
+					int32_t k = m.acol[e];
+					if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)k * nwin1; lo = bw[wa]; len = bw[wb] - lo; }
+					else { lo = m.bptr[k]; len = m.bptr[k + 1] - lo; }
+					a = m.aval[e];
+				}
 			}
-			__syncthreads();
-		}
-		digest_flush<NT>(sk.digest, cnt, hash, vs, s_u64, s_f64);
-	} else {
-		// compact the surviving (col, slot) pairs, bitonic-sort them by column, emit in order
-		uint32_t run = 0;
-		for (int base = 0; base < T; base += NT) {
-			int q = base + tid;
-			int32_t col = h_key[q];
-			double v = 0;
-			bool ok = col >= 0 && emit_value(ep, a_scale, col, h_val[q], &v);
-			if (ok) h_val[q] = v;
-			uint32_t total;
-			uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, scr32, &total);
-			if (ok) s_sort[run + ex] = ((uint64_t)(uint32_t)col << 16) | (uint64_t)q;
-			run += total;
-		}
-		const uint32_t mcount = run;
-		uint32_t n2 = 1;
-		while (n2 < mcount) n2 <<= 1;
-		for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
-		__syncthreads();
-		for (uint32_t k = 2; k <= n2; k <<= 1) {
-			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-				for (uint32_t i = tid; i < n2; i += NT) {
-					uint32_t ixj = i ^ j;
-					if (ixj > i) {
-						uint64_t x = s_sort[i], y = s_sort[ixj];
-						bool up = (i & k) == 0;
-						if ((x > y) == up) { s_sort[i] = y; s_sort[ixj] = x; }
+			uint32_t total, nzc;
+			expand_load(X, lo, len, a, &total, &nzc, flip);
+			if (total == 0) continue;
+			expand_batch(X, 0, total, nzc);
+			constexpr int U = 2;
+			for (uint32_t pbase = 0; pbase < total; pbase += NT * U) {
+				// U products per thread and step: issue all B loads before the first insertion
+				int32_t col[U]; double pv[U]; bool ok[U];
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					uint32_t p = pbase + u * NT + tid;
+					ok[u] = p < total;
+					p = ok[u] ? p : total - 1;
+					uint32_t q = expand_lookup(X, p, 0);
+					uint32_t bp = X.cstart[q] + (p - X.cpref[q]);
+					col[u] = m.bcol[bp];
+					pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * m.bval[bp] : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < U; ++u) {
+					bool isnew = false;
+					uint32_t h = 0;
+					if (ok[u]) {
+						h = ((uint32_t)col[u] * 0x9E3779B1u) >> (32 - LOGT);
+						for (;;) {
+							int32_t old = atomicCAS(&h_key[h], -1, col[u]);
+							if (old == -1) { isnew = true; break; }
+							if (old == col[u]) break;
+							h = (h + 1) & (T - 1);
+						}
+						if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
+					}
+					// append the newly occupied slots (one LDS atomic per wave)
+					uint64_t nm = __ballot(isnew);
+					if (nm) {
+						uint32_t base = 0;
+						if (lane_id() == 0) base = atomicAdd(&s_nocc, (uint32_t)__popcll(nm));
+						base = (uint32_t)__shfl((int)base, 0, 64);
+						if (isnew) occ[base + __popcll(nm & lanemask_lt())] = (uint16_t)h;
 					}
 				}
-				__syncthreads();
 			}
+			lds_barrier();
 		}
-		uint32_t seg = sk.segbase[r];
-		int64_t o = sk.segoff[seg];
-		for (uint32_t i = tid; i < mcount; i += NT) {
-			uint64_t kq = s_sort[i];
-			sk.out_i[o + i] = rowid;
-			sk.out_j[o + i] = (int32_t)(kq >> 16);
-			sk.out_v[o + i] = h_val[kq & 0xFFFFu];
+		// stage C of the pipeline: B segment bounds of the next cell's first chunk
+		nlo = 0; nlen = 0;
+		if (nact) {
+			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1; nlo = bw[rec1.wa]; nlen = bw[rec1.wb] - nlo; }
+			else { nlo = m.bptr[nk]; nlen = m.bptr[nk + 1] - nlo; }
+		} else na = 0;
+		lds_barrier();
+		const uint32_t nocc = s_nocc;
+		const double a_scale = row_scale(ep, rowid);
+		if (MODE == MODE_COUNT) {
+			// structural count (an upper bound when sums cancel to exactly 0)
+			uint32_t c = 0;
+			for (uint32_t i = tid; i < nocc; i += NT) { uint32_t h = occ[i]; if (col_allowed(ep, h_key[h])) ++c; h_key[h] = -1; }
+			uint32_t total;
+			block_exclusive_scan<uint32_t, NT>(c, scr32, &total);
+			if (tid == 0) sk.segcount[seg] = total;
+		} else if (MODE == MODE_DIGEST) {
+			unsigned long long cnt = 0; double vs = 0;
+			for (uint32_t i = tid; i < nocc; i += NT) {
+				uint32_t h = occ[i];
+				int32_t col = h_key[h];
+				double v;
+				if (emit_value(ep, a_scale, col, h_val[h], &v)) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+				h_key[h] = -1; h_val[h] = 0.0;
+			}
+			d_cnt += cnt; d_sum += vs;
+			if (sk.row_nnz) {
+				unsigned long long rc = wave_reduce_sum(cnt); double rs = wave_reduce_sum(vs);
+				if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+			}
+		} else {
+			// surviving (col, slot) pairs -> bitonic sort by column -> emit in order, cleaning the table
+			uint32_t run = 0;
+			for (uint32_t base = 0; base < nocc; base += NT) {
+				uint32_t i = base + tid;
+				bool ok = false;
+				uint32_t h = 0; int32_t col = 0;
+				if (i < nocc) {
+					h = occ[i]; col = h_key[h];
+					double v = 0;
+					ok = emit_value(ep, a_scale, col, h_val[h], &v);
+					h_key[h] = -1;
+					h_val[h] = ok ? v : 0.0;
+				}
+				uint32_t total;
+				uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, scr32, &total);
+				if (ok) s_sort[run + ex] = ((uint64_t)(uint32_t)col << 16) | (uint64_t)h;
+				run += total;
+			}
+			const uint32_t mcount = run;
+			uint32_t n2 = 1;
+			while (n2 < mcount) n2 <<= 1;
+			for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
+			__syncthreads();
+			for (uint32_t k = 2; k <= n2; k <<= 1) {
+				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+					for (uint32_t i = tid; i < n2; i += NT) {
+						uint32_t ixj = i ^ j;
+						if (ixj > i) {
+							uint64_t x = s_sort[i], y = s_sort[ixj];
+							bool up = (i & k) == 0;
+							if ((x > y) == up) { s_sort[i] = y; s_sort[ixj] = x; }
+						}
+					}
+					__syncthreads();
+				}
+			}
+			int64_t o = sk.segoff[seg];
+			for (uint32_t i = tid; i < mcount; i += NT) {
+				uint64_t kq = s_sort[i];
+				uint32_t h = (uint32_t)(kq & 0xFFFFu);
+				sk.out_i[o + i] = rowid;
+				sk.out_j[o + i] = (int32_t)(kq >> 16);
+				sk.out_v[o + i] = h_val[h];
+				h_val[h] = 0.0;
+			}
+			if (tid == 0) sk.segactual[seg] = mcount;
 		}
-		if (tid == 0) sk.segactual[seg] = mcount;
 	}
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
 }
 
-// ====================================================================== heavy rows (dense column windows in LDS)
+// ====================================================================== heavy rows: window index, cells
 
 // Window index of B: bwin[k * (nwin+1) + w] = first tuple of B row k whose
 // column is >= w * W  (bwin[k][0] = bptr[k], bwin[k][nwin] = bptr[k+1]).
@@ -481,188 +664,279 @@ __global__ void k_bwin_fill(const int32_t *brow, const int32_t *bcol, const uint
 	for (int ww = wprev + 1; ww <= w; ++ww) bwin[(uint64_t)k * nwin1 + ww] = e;
 }
 
-// One wave per heavy row: first / last window its products can touch.
-__global__ __launch_bounds__(64) void k_heavy_span(const uint32_t *hrows, uint32_t nheavy, RowMeta m, uint32_t wshift,
-	uint32_t *hwlo, uint32_t *hnwin)
+// Per heavy row: products per column window.  One workgroup per row; lanes run
+// over the windows of one A tuple (coalesced reads of its bwin row).
+constexpr int WH_NT = 256;
+constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
+__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint32_t *bwin,
+	uint32_t nwin, uint32_t *winprod)
 {
-	uint32_t h = blockIdx.x;
-	uint32_t r = hrows[h];
-	uint32_t beg = m.beg[r], end = m.beg[r + 1];
-	uint32_t cmin = 0xFFFFFFFFu, cmax = 0;
-	for (uint32_t e = beg + threadIdx.x; e < end; e += 64) {
-		int32_t k = m.acol[e];
-		uint32_t lo = m.bptr[k], hi = m.bptr[k + 1];
-		if (hi > lo) { cmin = min(cmin, (uint32_t)m.bcol[lo]); cmax = max(cmax, (uint32_t)m.bcol[hi - 1]); }
+	__shared__ uint32_t s_cnt[WH_MAXW];
+	const uint32_t h = blockIdx.x, r = hrows[h];
+	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
+	const uint32_t nwin1 = nwin + 1;
+	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) s_cnt[w] = 0;
+	__syncthreads();
+	// sub-groups of threads take different tuples when there are fewer windows than threads
+	uint32_t wpad = 1;
+	while (wpad < nwin && wpad < WH_NT) wpad <<= 1;
+	const uint32_t nsub = wpad < WH_NT ? WH_NT / wpad : 1;
+	const uint32_t sub = threadIdx.x / wpad, w0 = threadIdx.x % wpad;
+	if (nsub > 1) {
+		uint32_t cnt = 0;
+		if (w0 < nwin)
+			for (uint32_t e = beg + sub; e < end; e += nsub) {
+				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
+				cnt += bw[w0 + 1] - bw[w0];
+			}
+		if (w0 < nwin && cnt) atomicAdd(&s_cnt[w0], cnt);
+	} else {
+		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) {
+			uint32_t cnt = 0;
+			for (uint32_t e = beg; e < end; ++e) {
+				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
+				cnt += bw[w + 1] - bw[w];
+			}
+			s_cnt[w] = cnt;
+		}
 	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, d, 64));
-		cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-	}
-	if (threadIdx.x == 0) {
-		uint32_t wlo = cmin >> wshift, whi = cmax >> wshift;
-		hwlo[h] = wlo;
-		hnwin[h] = whi - wlo + 1;
-	}
+	__syncthreads();
+	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
 }
 
-__global__ void k_heavy_keys(const uint32_t *hrows, const uint32_t *rprod, uint32_t nheavy, uint64_t *keys)
+// Cell classes: 0..2 hash (T = 1024 / 4096 / 8192), 3 dense
+constexpr int NCLS = 4;
+constexpr uint32_t CELL_CAP = 4096;      // largest hash cell (T = 8192)
+constexpr uint32_t CELL_CAP_DEFAULT = 2048;
+__device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 2048 ? 1 : 2); }
+
+struct CellBases { uint32_t *base[NCLS]; };      // per heavy row: first cell index in each class list
+struct CellLists { Cell *list[NCLS]; };
+
+// Greedy grouping of a heavy row's windows into cells.  WRITE = false counts
+// the cells per class (and the row's segment count); WRITE = true emits them.
+template <bool WRITE>
+__global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
+	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap,
+	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod)
 {
 	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-	if (h < nheavy) keys[h] = (uint64_t)(0xFFFFFFFFu - rprod[hrows[h]]);     // descending P
+	if (h >= nheavy) return;
+	const uint32_t r = hrows[h];
+	Cell proto;
+	proto.beg = rbeg[r]; proto.end = rbeg[r + 1]; proto.rowid = rid[r]; proto.pad[0] = proto.pad[1] = 0;
+	const uint32_t *wp = winprod + (uint64_t)h * nwin;
+	uint32_t n[NCLS] = {0, 0, 0, 0};
+	unsigned long long np[NCLS] = {0, 0, 0, 0};
+	uint32_t ordinal = 0;
+	uint32_t cur = 0, start = 0, last = 0;
+	auto flush = [&]() {
+		if (!cur) return;
+		int cls = hash_class(cur);
+		if (WRITE) {
+			Cell c = proto; c.seg = segbase ? segbase[r] + ordinal : 0; c.prods = cur; c.wa = (uint16_t)start; c.wb = (uint16_t)(last + 1);
+			lists.list[cls][base.base[cls][h] + n[cls]] = c;
+		}
+		++n[cls]; np[cls] += cur; ++ordinal; cur = 0;
+	};
+	for (uint32_t w = 0; w < nwin; ++w) {
+		uint32_t c = wp[w];
+		if (c > cell_cap) {
+			flush();
+			if (WRITE) {
+				Cell d = proto; d.seg = segbase ? segbase[r] + ordinal : 0; d.prods = c; d.wa = (uint16_t)w; d.wb = (uint16_t)(w + 1);
+				lists.list[3][base.base[3][h] + n[3]] = d;
+			}
+			++n[3]; np[3] += c; ++ordinal;
+		} else if (c > 0) {
+			if (cur + c > cell_cap) flush();
+			if (!cur) start = w;
+			cur += c; last = w;
+		}
+	}
+	flush();
+	if (!WRITE) {
+#pragma unroll
+		for (int k = 0; k < NCLS; ++k) { cnt.base[k][h] = n[k]; if (np[k]) atomicAdd(&clsprod[k], np[k]); }
+		nseg[r] = ordinal;
+	}
 }
 
-__global__ void k_gather_u32(const uint32_t *src, const uint32_t *perm, uint32_t n, uint32_t *dst)
+__global__ void k_cell_keys(const Cell *cells, uint32_t n, int by_size, uint64_t *keys)
+{
+	// window-major; inside a window the largest cells first (dense) or input order (hash: stable sort)
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint64_t w = cells[i].wa;
+	keys[i] = by_size ? ((w << 32) | (uint64_t)(0xFFFFFFFFu - cells[i].prods)) : w;
+}
+
+__global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n, Cell *dst)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) dst[i] = src[perm[i]];
 }
 
-// nseg per non-empty row: 1, or the window count of a heavy row
-__global__ void k_nseg_heavy(const uint32_t *hrows, const uint32_t *hnwin, uint32_t nheavy, uint32_t *nseg)
-{
-	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-	if (h < nheavy) nseg[hrows[h]] = hnwin[h];
-}
+// ====================================================================== dense cells (f64 window accumulator in LDS)
 
+// Persistent workgroups pull dense cells (one window of one row, > 4096
+// products) from a ticket, largest first.
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(NT) void k_heavy(const uint32_t *hrows, const uint32_t *hwlo, const uint32_t *hnwin, uint32_t nheavy,
-	uint32_t *ticket, RowMeta m, const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
+__global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, uint32_t *ticket, RowMeta m,
+	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
 	constexpr int NW = NT / 64;
 	constexpr int NGRP = W / 64;             // 64-slot groups per window
 	constexpr int GPW = NGRP / NW;           // groups per wave
 	constexpr uint32_t WSHIFT = W == 8192 ? 13 : 14;
 	__shared__ double acc[W];
-	__shared__ uint8_t dirty[NGRP];
-	__shared__ uint32_t epref[NT + 1];
-	__shared__ uint32_t estart[NT];
-	__shared__ double eaval[NT];
-	__shared__ uint32_t scr32[NW + 1];
+	__shared__ Expand<NT, W> X;
 	__shared__ uint32_t s_wcnt[NW + 1];
-	__shared__ uint32_t s_ticket;
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
 
 	const unsigned tid = threadIdx.x, lane = lane_id(), wv = wave_id();
 	for (int q = tid; q < W; q += NT) acc[q] = 0.0;
-	for (int q = tid; q < NGRP; q += NT) dirty[q] = 0;
 	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
+	uint32_t flip = 0;
 
-	for (;;) {
-		__syncthreads();
-		if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
-		__syncthreads();
-		const uint32_t h = s_ticket;
-		if (h >= nheavy) break;                                     // every workgroup reaches this
-		const uint32_t r = hrows[h];
-		const uint32_t beg = m.beg[r], end = m.beg[r + 1];
-		const int32_t rowid = m.id[r];
+	// Cells are ordered by (window, descending products) and dealt with a grid stride, so the
+	// workgroups are on the same few column windows of B at any time (B's window slice is served
+	// from L2 / Infinity Cache) and every workgroup gets a mix of large and small cells.
+	// Same three-stage software pipeline as k_hash.
+	const uint32_t stride = gridDim.x;
+	Cell rec1{}, rec2{};
+	if (blockIdx.x < ncell) rec1 = cells[blockIdx.x];
+	if (blockIdx.x + stride < ncell) rec2 = cells[blockIdx.x + stride];
+	uint32_t nlo = 0, nlen = 0; double na = 0;
+	{
+		uint32_t e = rec1.beg + tid;
+		if (blockIdx.x < ncell && e < rec1.end) {
+			const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1 + rec1.wa;
+			nlo = bw[0]; nlen = bw[1] - nlo;
+			na = m.aval[e];
+		}
+	}
+	for (uint32_t ci = blockIdx.x; ci < ncell; ci += stride) {
+		const Cell cell = rec1;
+		const uint32_t w = cell.wa;
+		const uint32_t beg = cell.beg, end = cell.end;
+		const int32_t rowid = cell.rowid;
 		const double a_scale = row_scale(ep, rowid);
-		const uint32_t wlo = hwlo[h], nw = hnwin[h];
-		const uint32_t seg0 = (MODE == MODE_DIGEST) ? 0u : sk.segbase[r];
-		unsigned long long r_cnt = 0; double r_sum = 0;            // row statistics
+		const uint32_t wbase = w << WSHIFT;
+		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
+		rec1 = rec2;
+		if (ci + 2 * stride < ncell) rec2 = cells[ci + 2 * stride];
+		int32_t nk = 0; bool nact = false;
+		if (ci + stride < ncell) {
+			uint32_t e = rec1.beg + tid;
+			nact = e < rec1.end;
+			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
+		}
+		lds_barrier();                                              // previous cell's scan-out complete
 
-		for (uint32_t wi = 0; wi < nw; ++wi) {
-			const uint32_t w = wlo + wi;
-			const uint32_t wbase = w << WSHIFT;
-			bool any = false;
-			for (uint32_t chunk = beg; chunk < end; chunk += NT) {
+		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
+			uint32_t lo = lo0, len = len0; double a = a0;
+			if (chunk != beg) {
 				uint32_t e = chunk + tid;
-				uint32_t lo = 0, len = 0; double a = 0;
+				lo = 0; len = 0; a = 0;
 				if (e < end) {
 					int32_t k = m.acol[e];
 					const uint32_t *bw = bwin + (uint64_t)k * nwin1 + w;
 					lo = bw[0]; len = bw[1] - lo;
 					a = m.aval[e];
 				}
-				uint32_t total;
-				uint32_t ex = block_exclusive_scan<uint32_t, NT>(len, scr32, &total);
-				if (total == 0) continue;                           // uniform
-				any = true;
-				epref[tid] = ex; estart[tid] = lo; eaval[tid] = a;
-				if (tid == 0) epref[NT] = total;
-				__syncthreads();
-				for (uint32_t p = tid; p < total; p += NT) {
-					uint32_t q = find_entry<NT>(epref, p);
-					uint32_t bp = estart[q] + (p - epref[q]);
-					uint32_t slot = (uint32_t)m.bcol[bp] - wbase;
-					if (MODE == MODE_COUNT) acc[slot] = 1.0;        // structural: touched
-					else atomicAdd(&acc[slot], eaval[q] * m.bval[bp]);
-					dirty[slot >> 6] = 1;
-				}
-				__syncthreads();
 			}
-			if (!any) {
-				if (MODE == MODE_COUNT && tid == 0) sk.segcount[seg0 + wi] = 0;
-				if (MODE == MODE_STORE && tid == 0) sk.segactual[seg0 + wi] = 0;
-				continue;
-			}
-			// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
-			double v[GPW];
-			uint64_t nzmask[GPW];
-			uint32_t wcount = 0;
+			uint32_t total, nzc;
+			expand_load(X, lo, len, a, &total, &nzc, flip);
+			if (total == 0) continue;                               // uniform
+			// products of the chunk in batches of W
+			for (uint32_t pb = 0; pb < total; pb += W) {
+				const uint32_t pe = min(total, pb + (uint32_t)W);
+				expand_batch(X, pb, pe, nzc);
+				// U products per thread and step: all B loads of a step are issued before the first
+				// is used (the loop is bound by load latency, not by bandwidth or issue rate).
+				// A thread past the end re-reads the last product with weight 0.
+				constexpr int U = 4;
+				for (uint32_t p0 = pb + tid; p0 < pe; p0 += NT * U) {
+					uint32_t bp[U]; double av[U];
 #pragma unroll
-			for (int gi = 0; gi < GPW; ++gi) {
-				int grp = wv * GPW + gi;
-				v[gi] = 0; nzmask[gi] = 0;
-				if (dirty[grp]) {                                   // wave-uniform
-					double x = acc[grp * 64 + lane];
-					acc[grp * 64 + lane] = 0.0;
-					int32_t col = (int32_t)(wbase + grp * 64 + lane);
-					bool ok;
-					if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, col);
-					else ok = emit_value(ep, a_scale, col, x, &x);
-					v[gi] = x;
-					nzmask[gi] = __ballot(ok);
-					wcount += (uint32_t)__popcll(nzmask[gi]);
-				}
-			}
-			if (MODE == MODE_DIGEST) {
-				for (int gi = 0; gi < GPW; ++gi) {
-					if ((nzmask[gi] >> lane) & 1ull) {
-						int32_t col = (int32_t)(wbase + (wv * GPW + gi) * 64 + lane);
-						++d_cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); d_sum += v[gi];
-						++r_cnt; r_sum += v[gi];
+					for (int u = 0; u < U; ++u) {
+						uint32_t p = p0 + u * NT;
+						const bool ok = p < pe;
+						p = ok ? p : pe - 1;
+						uint32_t q = expand_lookup(X, p, pb);
+						bp[u] = X.cstart[q] + (p - X.cpref[q]);
+						av[u] = ok ? X.caval[q] : 0.0;
+					}
+					uint32_t col[U]; double bv[U];
+#pragma unroll
+					for (int u = 0; u < U; ++u) { col[u] = (uint32_t)m.bcol[bp[u]]; if (MODE != MODE_COUNT) bv[u] = m.bval[bp[u]]; }
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						uint32_t slot = col[u] - wbase;
+						if (MODE == MODE_COUNT) acc[slot] = 1.0;    // structural: touched
+						else atomicAdd(&acc[slot], av[u] * bv[u]);
 					}
 				}
-				__syncthreads();                                    // all reads of dirty[] done
-				for (int q = tid; q < NGRP; q += NT) dirty[q] = 0;
-			} else {
-				if (lane == 0) s_wcnt[wv] = wcount;
-				__syncthreads();                                    // also: all reads of dirty[] done
-				uint32_t wbefore = 0, wtotal = 0;
-#pragma unroll
-				for (int q = 0; q < NW; ++q) { uint32_t t = s_wcnt[q]; if (q < (int)wv) wbefore += t; wtotal += t; }
-				for (int q = tid; q < NGRP; q += NT) dirty[q] = 0;
-				if (MODE == MODE_COUNT) {
-					if (tid == 0) sk.segcount[seg0 + wi] = wtotal;
-				} else {
-					int64_t o = sk.segoff[seg0 + wi] + wbefore;
-#pragma unroll
-					for (int gi = 0; gi < GPW; ++gi) {
-						uint64_t mk = nzmask[gi];
-						if ((mk >> lane) & 1ull) {
-							int64_t oo = o + __popcll(mk & lanemask_lt());
-							sk.out_i[oo] = rowid;
-							sk.out_j[oo] = (int32_t)(wbase + (wv * GPW + gi) * 64 + lane);
-							sk.out_v[oo] = v[gi];
-						}
-						o += __popcll(mk);
-					}
-					if (tid == 0) sk.segactual[seg0 + wi] = wtotal;
-				}
+				lds_barrier();
 			}
 		}
-		if (MODE == MODE_DIGEST && sk.row_nnz) {
-			unsigned long long rc = wave_reduce_sum(r_cnt); double rs = wave_reduce_sum(r_sum);
+		// stage C of the pipeline: B segment bounds of the next cell's first chunk
+		nlo = 0; nlen = 0;
+		if (nact) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1 + rec1.wa; nlo = bw[0]; nlen = bw[1] - nlo; } else na = 0;
+		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
+		double v[GPW];
+		uint64_t nzmask[GPW];
+		uint32_t wcount = 0;
+#pragma unroll
+		for (int gi = 0; gi < GPW; ++gi) {
+			int grp = wv * GPW + gi;
+			double x = acc[grp * 64 + lane];
+			acc[grp * 64 + lane] = 0.0;
+			int32_t col = (int32_t)(wbase + grp * 64 + lane);
+			bool ok;
+			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, col);
+			else ok = emit_value(ep, a_scale, col, x, &x);
+			v[gi] = x;
+			nzmask[gi] = __ballot(ok);
+			wcount += (uint32_t)__popcll(nzmask[gi]);
+		}
+		if (MODE == MODE_DIGEST) {
+			unsigned long long r_cnt = 0; double r_sum = 0;
+			for (int gi = 0; gi < GPW; ++gi) {
+				if ((nzmask[gi] >> lane) & 1ull) {
+					int32_t col = (int32_t)(wbase + (wv * GPW + gi) * 64 + lane);
+					++r_cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); r_sum += v[gi];
+				}
+			}
+			d_cnt += r_cnt; d_sum += r_sum;
+			if (sk.row_nnz) {
+				unsigned long long rc = wave_reduce_sum(r_cnt); double rs = wave_reduce_sum(r_sum);
+				if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+			}
+		} else {
+			if (lane == 0) s_wcnt[wv] = wcount;
 			__syncthreads();
-			if (lane == 0) { s_u64[wv] = rc; s_f64[wv] = rs; }
-			__syncthreads();
-			if (tid == 0) {
-				unsigned long long c = 0; double s = 0;
-				for (int q = 0; q < NW; ++q) { c += s_u64[q]; s += s_f64[q]; }
-				sk.row_nnz[rowid] = (long long)c; sk.row_sum[rowid] = s;
+			uint32_t wbefore = 0, wtotal = 0;
+#pragma unroll
+			for (int q = 0; q < NW; ++q) { uint32_t t = s_wcnt[q]; if (q < (int)wv) wbefore += t; wtotal += t; }
+			if (MODE == MODE_COUNT) {
+				if (tid == 0) sk.segcount[cell.seg] = wtotal;
+			} else {
+				int64_t o = sk.segoff[cell.seg] + wbefore;
+#pragma unroll
+				for (int gi = 0; gi < GPW; ++gi) {
+					uint64_t mk = nzmask[gi];
+					if ((mk >> lane) & 1ull) {
+						int64_t oo = o + __popcll(mk & lanemask_lt());
+						sk.out_i[oo] = rowid;
+						sk.out_j[oo] = (int32_t)(wbase + (wv * GPW + gi) * 64 + lane);
+						sk.out_v[oo] = v[gi];
+					}
+					o += __popcll(mk);
+				}
+				if (tid == 0) sk.segactual[cell.seg] = wtotal;
 			}
 		}
 	}
@@ -710,7 +984,7 @@ struct Bins {
 };
 
 template <int MODE>
-static void launch_light_mid(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+static void launch_light(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	hipStream_t st = c->stream;
 	if (b.count[1]) { k_light<8, MODE><<<dim3(grid_for(b.count[1], 32)), dim3(256), 0, st>>>(b.rows + b.off[1], b.count[1], m, ep, sk); SPS_LAUNCH_CHECK(); }
@@ -719,35 +993,77 @@ static void launch_light_mid(spsamd_ctx *c, const Bins &b, const RowMeta &m, con
 	if (b.count[4]) { k_light<64, MODE><<<dim3(grid_for(b.count[4], 4)), dim3(256), 0, st>>>(b.rows + b.off[4], b.count[4], m, ep, sk); SPS_LAUNCH_CHECK(); }
 }
 
-template <int MODE>
-static void launch_mid(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+template <int T, int NT, int MODE, bool WINDOWED>
+static void launch_hash(spsamd_ctx *c, const Cell *cells, uint32_t ncell, const RowMeta &m, const uint32_t *bwin, uint32_t nwin1,
+	const EmitParams &ep, const SinkParams &sk)
 {
-	hipStream_t st = c->stream;
-	if (b.count[5]) { k_mid<1024, MODE><<<dim3(b.count[5]), dim3(256), 0, st>>>(b.rows + b.off[5], b.count[5], m, ep, sk); SPS_LAUNCH_CHECK(); }
-	if (b.count[6]) { k_mid<4096, MODE><<<dim3(b.count[6]), dim3(256), 0, st>>>(b.rows + b.off[6], b.count[6], m, ep, sk); SPS_LAUNCH_CHECK(); }
-	if (b.count[7]) { k_mid<8192, MODE><<<dim3(b.count[7]), dim3(256), 0, st>>>(b.rows + b.off[7], b.count[7], m, ep, sk); SPS_LAUNCH_CHECK(); }
+	if (!ncell) return;
+	static int per_cu = 0;                     // resident workgroups per CU of this instantiation
+	if (!per_cu) {
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash<T, NT, MODE, WINDOWED>, NT, 0) != hipSuccess || nb < 1) nb = 1;
+		per_cu = nb;
+	}
+	unsigned grid = std::min<unsigned>(ncell, (unsigned)(c->num_cu * per_cu));
+	k_hash<T, NT, MODE, WINDOWED><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, m, bwin, nwin1, ep, sk);
+	SPS_LAUNCH_CHECK();
+}
+
+struct MidCells { Cell *cells[3] = {nullptr, nullptr, nullptr}; };
+
+template <int MODE>
+static void launch_mid(spsamd_ctx *c, const Bins &b, const MidCells &mc, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+{
+	launch_hash<1024, 256, MODE, false>(c, mc.cells[0], b.count[5], m, nullptr, 0, ep, sk);
+	launch_hash<4096, 256, MODE, false>(c, mc.cells[1], b.count[6], m, nullptr, 0, ep, sk);
+	launch_hash<8192, 256, MODE, false>(c, mc.cells[2], b.count[7], m, nullptr, 0, ep, sk);
 }
 
 struct Heavy {
-	uint32_t n = 0;
-	uint32_t *rows = nullptr, *wlo = nullptr, *nwin = nullptr;
+	uint32_t n = 0;                  // heavy rows
+	uint32_t *rows = nullptr;
 	uint32_t *bwin = nullptr;
-	uint32_t nwin1 = 0;
+	uint32_t nwin = 0, nwin1 = 0;
+	uint32_t *winprod = nullptr;
+	uint32_t ncell[NCLS] = {0, 0, 0, 0};
+	Cell *cells[NCLS] = {nullptr, nullptr, nullptr, nullptr};
+	CellBases cnt{}, base{};
 	uint32_t *ticket = nullptr;
 	int W = 8192;
+	uint32_t cell_cap = CELL_CAP_DEFAULT;
+	unsigned long long clsprod[NCLS] = {0, 0, 0, 0};
 };
 
 template <int MODE>
-static void launch_heavy(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
-	if (!hv.n) return;
+	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], m, hv.bwin, hv.nwin1, ep, sk);
+	static const int hnt = getenv("SPSAMD_HASH_NT") ? atoi(getenv("SPSAMD_HASH_NT")) : 512;
+	if (hnt == 1024) {
+		launch_hash<4096, 1024, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<8192, 1024, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+		return;
+	}
+	if (hnt == 512) {
+		launch_hash<4096, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<8192, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+		return;
+	}
+	launch_hash<4096, 256, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<8192, 256, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+}
+
+template <int MODE>
+static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+{
+	if (!hv.ncell[3]) return;
 	fill_zero(c, hv.ticket, sizeof(uint32_t));
 	if (hv.W == 8192) {
-		unsigned grid = std::min<unsigned>(hv.n, (unsigned)c->num_cu * 2u);
-		k_heavy<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.rows, hv.wlo, hv.nwin, hv.n, hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
+		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu * 2u);
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
 	} else {
-		unsigned grid = std::min<unsigned>(hv.n, (unsigned)c->num_cu);
-		k_heavy<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.rows, hv.wlo, hv.nwin, hv.n, hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
+		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu);
+		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
 	}
 	SPS_LAUNCH_CHECK();
 }
@@ -757,6 +1073,64 @@ static float elapsed(hipEvent_t a, hipEvent_t b)
 	float ms = 0;
 	SPS_HIP(hipEventElapsedTime(&ms, a, b));
 	return ms;
+}
+
+// Heavy rows: window index of B, per-row window histogram, counting pass of the cell grouping.
+static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
+	uint32_t extra, uint32_t *nseg)
+{
+	hipStream_t st = c->stream;
+	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
+	const uint32_t wshift = hv.W == 8192 ? 13 : 14;
+	hv.nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
+	if (hv.nwin > (uint32_t)WH_MAXW) throw Error{SPSAMD_EINVAL, "too many column windows (ncol > 2^25) for the heavy-row path"};
+	hv.nwin1 = hv.nwin + 1;
+	const uint64_t nrowb = B.nrow + extra;
+	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
+	k_bwin_prefill<<<dim3(4096), dim3(256), 0, st>>>(bptr, nrowb, hv.nwin1, hv.bwin);
+	SPS_LAUNCH_CHECK();
+	k_bwin_fill<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, bptr, B.nnz, wshift, hv.nwin1, hv.bwin);
+	SPS_LAUNCH_CHECK();
+	hv.rows = bins.rows + bins.off[8];
+	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, hv.bwin, hv.nwin, hv.winprod);
+	SPS_LAUNCH_CHECK();
+	for (int k = 0; k < NCLS; ++k) {
+		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
+		hv.base.base[k] = c->arena.get<uint32_t>((size_t)hv.n + 1);
+	}
+	if (const char *e = getenv("SPSAMD_CELL_CAP")) { int v = atoi(e); if (v >= 64 && v <= (int)CELL_CAP) hv.cell_cap = (uint32_t)v; }
+	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
+	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod);
+	SPS_LAUNCH_CHECK();
+	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
+	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
+	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
+	hv.ticket = c->arena.get<uint32_t>(1);
+}
+
+// Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.
+static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase)
+{
+	hipStream_t st = c->stream;
+	CellLists lists;
+	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.cnt, nullptr, hv.base, lists, segbase, nullptr);
+	SPS_LAUNCH_CHECK();
+	for (int k = 0; k < NCLS; ++k) {
+		uint32_t nd = hv.ncell[k];
+		if (nd < 2) continue;
+		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
+		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
+		k_cell_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == 3, k0);
+		SPS_LAUNCH_CHECK();
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == 3 ? 44 : 12);
+		Cell *sorted = c->arena.get<Cell>(nd);
+		k_gather_cells<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], where ? p1 : p0, nd, sorted);
+		SPS_LAUNCH_CHECK();
+		hv.cells[k] = sorted;
+	}
 }
 
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
@@ -829,42 +1203,42 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val};
 
-	// ---- heavy rows: window index of B, window span per row, heaviest first
+	// ---- segments (one per light/mid row, one per cell of a heavy row) and the heavy rows' cells
+	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
+	uint32_t *nseg = c->arena.get<uint32_t>(rl.nrows);
+	fill_u32(c, nseg, 1u, rl.nrows);
 	Heavy hv;
 	hv.n = bins.count[8];
-	if (hv.n) {
-		hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
-		const uint32_t wshift = hv.W == 8192 ? 13 : 14;
-		const uint32_t nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
-		hv.nwin1 = nwin + 1;
-		const uint64_t nrowb = B.nrow + extra;
-		hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
-		k_bwin_prefill<<<dim3(4096), dim3(256), 0, st>>>(bptr, nrowb, hv.nwin1, hv.bwin);
-		SPS_LAUNCH_CHECK();
-		k_bwin_fill<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, bptr, B.nnz, wshift, hv.nwin1, hv.bwin);
-		SPS_LAUNCH_CHECK();
-		// sort the heavy rows by descending product count so the longest rows start first
-		uint32_t *hraw = bins.rows + bins.off[8];
-		uint64_t *k0 = c->arena.get<uint64_t>(hv.n), *k1 = c->arena.get<uint64_t>(hv.n);
-		uint32_t *p0 = c->arena.get<uint32_t>(hv.n), *p1 = c->arena.get<uint32_t>(hv.n);
-		k_heavy_keys<<<dim3(grid_for(hv.n)), dim3(256), 0, st>>>(hraw, rprod, hv.n, k0);
-		SPS_LAUNCH_CHECK();
-		int where = radix_sort_pairs(c, k0, p0, k1, p1, hv.n, 32);
-		hv.rows = c->arena.get<uint32_t>(hv.n);
-		k_gather_u32<<<dim3(grid_for(hv.n)), dim3(256), 0, st>>>(hraw, where ? p1 : p0, hv.n, hv.rows);
-		SPS_LAUNCH_CHECK();
-		hv.wlo = c->arena.get<uint32_t>(hv.n);
-		hv.nwin = c->arena.get<uint32_t>(hv.n);
-		k_heavy_span<<<dim3(hv.n), dim3(64), 0, st>>>(hv.rows, hv.n, m, wshift, hv.wlo, hv.nwin);
-		SPS_LAUNCH_CHECK();
-		hv.ticket = c->arena.get<uint32_t>(1);
+	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg);
+	uint32_t *segbase = nullptr;
+	int64_t nsegs = 0;
+	if (coo) {
+		int64_t *segbase64 = c->arena.get<int64_t>((size_t)rl.nrows + 1);
+		scan_exclusive_u32_i64(c, nseg, segbase64, rl.nrows);
+		nsegs = read_back(c, segbase64 + rl.nrows);
+		if (nsegs >= (int64_t(1) << 32)) throw Error{SPSAMD_EINVAL, "too many output segments"};
+		segbase = c->arena.get<uint32_t>((size_t)rl.nrows + 1);
+		scan_exclusive_u32_u32(c, nseg, segbase, rl.nrows);
 	}
+	if (hv.n) heavy_cells(c, hv, m, segbase);
+	MidCells mc;
+	for (int k = 0; k < 3; ++k) {
+		uint32_t nb = bins.count[5 + k];
+		if (!nb) continue;
+		mc.cells[k] = c->arena.get<Cell>(nb);
+		k_row_cells<<<dim3(grid_for(nb)), dim3(256), 0, st>>>(bins.rows + bins.off[5 + k], nb, rl.beg, rl.id, rprod, segbase, mc.cells[k]);
+		SPS_LAUNCH_CHECK();
+	}
+	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2];
+	res->cells_dense = hv.ncell[3];
+	res->products_dense = hv.clsprod[3];
 	SPS_HIP(hipEventRecord(c->ev[2], st));
 
 	// ---- numeric
 	SinkParams sk{};
-	float ms_light = 0, ms_mid = 0, ms_heavy = 0;
-	if (a.sink_kind == SPSAMD_SINK_DIGEST) {
+	sk.segbase = segbase;
+	float ms_light = 0, ms_mid = 0, ms_heavy = 0, ms_dense = 0;
+	if (!coo) {
 		DigestSlot *slots = c->arena.get<DigestSlot>(DIGEST_SLOTS + 1);
 		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
 		sk.digest = slots;
@@ -879,42 +1253,33 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 			res->row_sum = sk.row_sum;
 		}
 		SPS_HIP(hipEventRecord(c->ev[3], st));
-		launch_light_mid<MODE_DIGEST>(c, bins, m, ep, sk);
+		launch_light<MODE_DIGEST>(c, bins, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[4], st));
-		launch_mid<MODE_DIGEST>(c, bins, m, ep, sk);
+		launch_mid<MODE_DIGEST>(c, bins, mc, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[5], st));
-		launch_heavy<MODE_DIGEST>(c, hv, m, ep, sk);
+		launch_heavy_hash<MODE_DIGEST>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[6], st));
+		launch_heavy_dense<MODE_DIGEST>(c, hv, m, ep, sk);
+		SPS_HIP(hipEventRecord(c->ev[8], st));
 		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS);
 		SPS_LAUNCH_CHECK();
 		DigestSlot d = read_back(c, slots + DIGEST_SLOTS);
 		res->nnz = d.count; res->hash = d.hash; res->sum = d.sum;
-		ms_light = elapsed(c->ev[3], c->ev[4]); ms_mid = elapsed(c->ev[4], c->ev[5]); ms_heavy = elapsed(c->ev[5], c->ev[6]);
+		ms_light = elapsed(c->ev[3], c->ev[4]); ms_mid = elapsed(c->ev[4], c->ev[5]);
+		ms_heavy = elapsed(c->ev[5], c->ev[8]); ms_dense = elapsed(c->ev[6], c->ev[8]);
 	} else {
-		// segments: one per row, one per (heavy row, window); reserve, scan, store
-		uint32_t *nseg = c->arena.get<uint32_t>(rl.nrows);
-		fill_u32(c, nseg, 1u, rl.nrows);
-		if (hv.n) {
-			k_nseg_heavy<<<dim3(grid_for(hv.n)), dim3(256), 0, st>>>(hv.rows, hv.nwin, hv.n, nseg);
-			SPS_LAUNCH_CHECK();
-		}
-		int64_t *segbase64 = c->arena.get<int64_t>((size_t)rl.nrows + 1);
-		scan_exclusive_u32_i64(c, nseg, segbase64, rl.nrows);
-		int64_t nsegs = read_back(c, segbase64 + rl.nrows);
-		if (nsegs >= (int64_t(1) << 32)) throw Error{SPSAMD_EINVAL, "too many output segments"};
-		uint32_t *segbase = c->arena.get<uint32_t>((size_t)rl.nrows + 1);
-		scan_exclusive_u32_u32(c, nseg, segbase, rl.nrows);
-		uint32_t *segcount = c->arena.get<uint32_t>((size_t)nsegs);
-		uint32_t *segactual = c->arena.get<uint32_t>((size_t)nsegs);
+		uint32_t *segcount = c->arena.get<uint32_t>((size_t)nsegs + 1);
+		uint32_t *segactual = c->arena.get<uint32_t>((size_t)nsegs + 1);
 		int64_t *segoff = c->arena.get<int64_t>((size_t)nsegs + 1);
-		fill_zero(c, segcount, (size_t)nsegs * sizeof(uint32_t));
-		fill_zero(c, segactual, (size_t)nsegs * sizeof(uint32_t));
-		sk.segbase = segbase; sk.segcount = segcount; sk.segoff = segoff; sk.segactual = segactual;
+		fill_zero(c, segcount, ((size_t)nsegs + 1) * sizeof(uint32_t));
+		fill_zero(c, segactual, ((size_t)nsegs + 1) * sizeof(uint32_t));
+		sk.segcount = segcount; sk.segoff = segoff; sk.segactual = segactual;
 
 		SPS_HIP(hipEventRecord(c->ev[3], st));
-		launch_light_mid<MODE_COUNT>(c, bins, m, ep, sk);
-		launch_mid<MODE_COUNT>(c, bins, m, ep, sk);
-		launch_heavy<MODE_COUNT>(c, hv, m, ep, sk);
+		launch_light<MODE_COUNT>(c, bins, m, ep, sk);
+		launch_mid<MODE_COUNT>(c, bins, mc, m, ep, sk);
+		launch_heavy_hash<MODE_COUNT>(c, hv, m, ep, sk);
+		launch_heavy_dense<MODE_COUNT>(c, hv, m, ep, sk);
 		scan_exclusive_u32_i64(c, segcount, segoff, (size_t)nsegs);
 		int64_t reserved = read_back(c, segoff + nsegs);
 		c->out_i.ensure((size_t)reserved * sizeof(int32_t));
@@ -922,11 +1287,13 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		c->out_v.ensure((size_t)reserved * sizeof(double));
 		sk.out_i = (int32_t *)c->out_i.p; sk.out_j = (int32_t *)c->out_j.p; sk.out_v = (double *)c->out_v.p;
 		SPS_HIP(hipEventRecord(c->ev[4], st));
-		launch_light_mid<MODE_STORE>(c, bins, m, ep, sk);
-		launch_mid<MODE_STORE>(c, bins, m, ep, sk);
+		launch_light<MODE_STORE>(c, bins, m, ep, sk);
+		launch_mid<MODE_STORE>(c, bins, mc, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[5], st));
-		launch_heavy<MODE_STORE>(c, hv, m, ep, sk);
+		launch_heavy_hash<MODE_STORE>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[6], st));
+		launch_heavy_dense<MODE_STORE>(c, hv, m, ep, sk);
+		SPS_HIP(hipEventRecord(c->ev[8], st));
 		unsigned long long *holes = c->arena.get<unsigned long long>(1);
 		fill_zero(c, holes, sizeof(unsigned long long));
 		k_seg_holes<<<dim3(grid_for((size_t)nsegs)), dim3(256), 0, st>>>(segcount, segactual, (uint32_t)nsegs, holes);
@@ -949,13 +1316,14 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		}
 		res->nnz = nnz;
 		res->idx0 = sk.out_i; res->idx1 = sk.out_j; res->val = sk.out_v;
-		ms_light = elapsed(c->ev[4], c->ev[5]); ms_heavy = elapsed(c->ev[5], c->ev[6]);
+		ms_light = elapsed(c->ev[4], c->ev[5]);
+		ms_heavy = elapsed(c->ev[5], c->ev[8]); ms_dense = elapsed(c->ev[6], c->ev[8]);
 	}
 	SPS_HIP(hipEventRecord(c->ev[7], st));
 	SPS_HIP(hipEventSynchronize(c->ev[7]));
 	res->ms_symbolic = elapsed(c->ev[1], c->ev[2]);
 	res->ms_numeric = elapsed(c->ev[2], c->ev[7]);
-	res->ms_light = ms_light; res->ms_mid = ms_mid; res->ms_heavy = ms_heavy;
+	res->ms_light = ms_light; res->ms_mid = ms_mid; res->ms_heavy = ms_heavy; res->ms_dense = ms_dense;
 }
 
 } // namespace spsamd
