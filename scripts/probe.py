@@ -31,12 +31,11 @@ def main():
         t = time.time()
         r = ctx.multiply(A, A, sink=sink)
         dt = time.time() - t
-        print("%s %d rep %d: wall %.1f ms | total %.2f cons %.2f symb %.2f num %.2f (light %.2f mid %.2f heavy %.2f) | "
-              "nnzA %d P %d nnzC %d | rows l/m/h %d/%d/%d prods l/m/h %.3g/%.3g/%.3g | cells hash/dense %d/%d dense-ms %.2f dense-prods %.3g | %.3g prod/s alg-read %.1f GB/s" % (
-                  kind, size, rep, dt * 1e3, r.ms_total, r.ms_consolidate, r.ms_symbolic, r.ms_numeric, r.ms_light, r.ms_mid,
-                  r.ms_heavy, r.nnz_a, r.products, r.nnz, r.rows_light, r.rows_mid, r.rows_heavy,
-                  r.products_light, r.products_mid, r.products_heavy, r.cells_hash, r.cells_dense, r.ms_dense, r.products_dense,
-                  r.products / (r.ms_total * 1e-3),
+        print("%s %d rep %d: total %.1f ms (cons %.1f symb %.1f light %.2f mid %.2f hash %.1f dense %.1f) "
+              "P %.3g nnzC %.3g | prods mid %.3g hash %.3g dense %.3g | cells hash %d dense %d | %.3g prod/s, %.0f GB/s alg-read" % (
+                  kind, size, rep, r.ms_total, r.ms_consolidate, r.ms_symbolic, r.ms_light, r.ms_mid, r.ms_heavy - r.ms_dense,
+                  r.ms_dense, r.products, r.nnz, r.products_mid, r.products_heavy - r.products_dense, r.products_dense,
+                  r.cells_hash, r.cells_dense, r.products / (r.ms_total * 1e-3),
                   (16 * r.nnz_a + 12 * r.products) / (r.ms_total * 1e-3) / 1e9), flush=True)
 
 

@@ -34,7 +34,9 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 		int32_t pr = major[i - 1], pc = minor[i - 1];
 		if (!(pr < r || (pr == r && pc < c))) f |= 2u;
 	}
-	if (f) atomicOr(flags, f);
+	// almost every thread of an unsorted operand raises bit 1: test the flag word before the
+	// atomic so the common case is a cached read, not a serialised same-address atomic
+	if (f && (*(volatile uint32_t *)flags & f) != f) atomicOr(flags, f);
 }
 
 __global__ void k_build_keys(const int32_t *major, const int32_t *minor, size_t n, int minor_bits, uint64_t *keys)

@@ -40,6 +40,7 @@ struct EmitParams {
 	double C;
 	const int32_t *si_pos; const double *si_val;     // row scale (null: none)
 	const int32_t *sk_pos; const double *sk_val;     // column scale (null: none)
+	int dbg;                                         // developer ablation switches (0 in production)
 };
 
 struct DigestSlot { unsigned long long count; unsigned long long hash; double sum; unsigned long long pad; };
@@ -518,8 +519,9 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			uint32_t total, nzc;
 			expand_load(X, lo, len, a, &total, &nzc, flip);
 			if (total == 0) continue;
-			expand_batch(X, 0, total, nzc);
+			if (!(ep.dbg & 4)) expand_batch(X, 0, total, nzc);
 			constexpr int U = 2;
+			if (ep.dbg & 1) total = 0;
 			for (uint32_t pbase = 0; pbase < total; pbase += NT * U) {
 				// U products per thread and step: issue all B loads before the first insertion
 				int32_t col[U]; double pv[U]; bool ok[U];
@@ -566,7 +568,8 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			else { nlo = m.bptr[nk]; nlen = m.bptr[nk + 1] - nlo; }
 		} else na = 0;
 		lds_barrier();
-		const uint32_t nocc = s_nocc;
+		uint32_t nocc = s_nocc;
+		if (ep.dbg & 2) nocc = 0;
 		const double a_scale = row_scale(ep, rowid);
 		if (MODE == MODE_COUNT) {
 			// structural count (an upper bound when sums cancel to exactly 0)
@@ -684,11 +687,22 @@ __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint3
 	const uint32_t sub = threadIdx.x / wpad, w0 = threadIdx.x % wpad;
 	if (nsub > 1) {
 		uint32_t cnt = 0;
-		if (w0 < nwin)
-			for (uint32_t e = beg + sub; e < end; e += nsub) {
+		if (w0 < nwin) {
+			// four A tuples per step: their index rows are fetched with independent loads
+			uint32_t e = beg + sub;
+			for (; e + 3 * nsub < end; e += 4 * nsub) {
+				const uint32_t *b0 = bwin + (uint64_t)m.acol[e] * nwin1 + w0;
+				const uint32_t *b1 = bwin + (uint64_t)m.acol[e + nsub] * nwin1 + w0;
+				const uint32_t *b2 = bwin + (uint64_t)m.acol[e + 2 * nsub] * nwin1 + w0;
+				const uint32_t *b3 = bwin + (uint64_t)m.acol[e + 3 * nsub] * nwin1 + w0;
+				uint32_t x0 = b0[0], y0 = b0[1], x1 = b1[0], y1 = b1[1], x2 = b2[0], y2 = b2[1], x3 = b3[0], y3 = b3[1];
+				cnt += (y0 - x0) + (y1 - x1) + (y2 - x2) + (y3 - x3);
+			}
+			for (; e < end; e += nsub) {
 				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
 				cnt += bw[w0 + 1] - bw[w0];
 			}
+		}
 		if (w0 < nwin && cnt) atomicAdd(&s_cnt[w0], cnt);
 	} else {
 		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) {
@@ -850,6 +864,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			uint32_t total, nzc;
 			expand_load(X, lo, len, a, &total, &nzc, flip);
 			if (total == 0) continue;                               // uniform
+			if (ep.dbg & 8) total = 0;
 			// products of the chunk in batches of W
 			for (uint32_t pb = 0; pb < total; pb += W) {
 				const uint32_t pe = min(total, pb + (uint32_t)W);
@@ -885,6 +900,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
 		nlo = 0; nlen = 0;
 		if (nact) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1 + rec1.wa; nlo = bw[0]; nlen = bw[1] - nlo; } else na = 0;
+		if (ep.dbg & 16) continue;
 		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
 		double v[GPW];
 		uint64_t nzmask[GPW];
@@ -1201,7 +1217,8 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->tuples_heavy = hbc.tuples[8];
 
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val};
-	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val};
+	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
+		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0};
 
 	// ---- segments (one per light/mid row, one per cell of a heavy row) and the heavy rows' cells
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
