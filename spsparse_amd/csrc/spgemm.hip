@@ -432,6 +432,44 @@ __device__ __forceinline__ uint32_t expand_lookup(const Expand<NT, PB> &L, uint3
 	return L.bq[b] + (uint32_t)__popcll(L.bmask[b] & ((2ull << j) - 1ull));
 }
 
+
+// XCD-aware walk of a cell list.  Workgroups are dispatched round-robin over the 8 XCDs
+// (blockIdx % 8 names the group of blocks that share an XCD and its L2).  The list, which is
+// in window-major order, is cut into 8 contiguous parts of equal cost (xb[0..8]); XCD group
+// x walks part x, so each L2 holds the B column-window slice of ITS part only instead of all
+// eight L2s fetching the same slice.  Speed only: any placement gives the same result.
+struct CellWalk { uint32_t first, end, stride; };
+__device__ __forceinline__ CellWalk cell_walk(const uint32_t *xb, uint32_t ncell)
+{
+	CellWalk w;
+	if (xb && (gridDim.x & 7u) == 0) {
+		uint32_t x = blockIdx.x & 7u;
+		w.first = xb[x] + (blockIdx.x >> 3);
+		w.end = xb[x + 1];
+		w.stride = gridDim.x >> 3;
+	} else {
+		w.first = blockIdx.x; w.end = ncell; w.stride = gridDim.x;
+	}
+	return w;
+}
+
+__global__ void k_cell_cost(const Cell *cells, uint32_t n, uint32_t fixed, uint32_t *cost)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cost[i] = cells[i].prods + fixed;
+}
+
+__global__ void k_xcd_bounds(const int64_t *pref, uint32_t n, uint32_t *xb)
+{
+	// xb[x] = first cell whose cost prefix reaches x/8 of the total
+	uint32_t x = threadIdx.x;
+	if (x > 8) return;
+	int64_t target = pref[n] / 8 * x;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (pref[mid] < target) lo = mid + 1; else hi = mid; }
+	xb[x] = x == 8 ? n : lo;
+}
+
 // Cells for the mid rows (P_r <= 4096): the whole row, no window index.
 __global__ void k_row_cells(const uint32_t *binrows, uint32_t n, const uint32_t *rbeg, const int32_t *rid, const uint32_t *rprod,
 	const uint32_t *segbase, Cell *cells)
@@ -451,7 +489,7 @@ __global__ void k_row_cells(const uint32_t *binrows, uint32_t n, const uint32_t 
 // is cleaned as it is emitted (list of occupied slots), so a cell costs work
 // proportional to its products, not to T.
 template <int T, int NT, int MODE, bool WINDOWED>
-__global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, RowMeta m,
+__global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
 	constexpr int LOGT = T == 1024 ? 10 : (T == 4096 ? 12 : 13);
@@ -473,30 +511,31 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 	// Software pipeline over the cells of this workgroup: the record of cell i+2, the A tuples of
 	// cell i+1 and then its B segment bounds are loaded while cell i is processed (the barriers
 	// inside are LDS-only, so these loads stay in flight).
-	const uint32_t stride = gridDim.x;
+	const CellWalk walk = cell_walk(xb, ncell);
+	const uint32_t stride = walk.stride, cend = walk.end;
 	Cell rec1{}, rec2{};
-	if (blockIdx.x < ncell) rec1 = cells[blockIdx.x];
-	if (blockIdx.x + stride < ncell) rec2 = cells[blockIdx.x + stride];
+	if (walk.first < cend) rec1 = cells[walk.first];
+	if (walk.first + stride < cend) rec2 = cells[walk.first + stride];
 	uint32_t nlo = 0, nlen = 0; double na = 0;
 	{
 		uint32_t e = rec1.beg + tid;
-		if (blockIdx.x < ncell && e < rec1.end) {
+		if (walk.first < cend && e < rec1.end) {
 			int32_t k = m.acol[e];
 			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)k * nwin1; nlo = bw[rec1.wa]; nlen = bw[rec1.wb] - nlo; }
 			else { nlo = m.bptr[k]; nlen = m.bptr[k + 1] - nlo; }
 			na = m.aval[e];
 		}
 	}
-	for (uint32_t ci = blockIdx.x; ci < ncell; ci += stride) {
+	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
 		const Cell cell = rec1;
 		const uint32_t beg = cell.beg, end = cell.end, wa = cell.wa, wb = cell.wb, seg = cell.seg;
 		const int32_t rowid = cell.rowid;
 		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
 		// stage A / B of the pipeline
 		rec1 = rec2;
-		if (ci + 2 * stride < ncell) rec2 = cells[ci + 2 * stride];
+		if (ci + 2 * stride < cend) rec2 = cells[ci + 2 * stride];
 		int32_t nk = 0; bool nact = false;
-		if (ci + stride < ncell) {
+		if (ci + stride < cend) {
 			uint32_t e = rec1.beg + tid;
 			nact = e < rec1.end;
 			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
@@ -796,7 +835,7 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 // Persistent workgroups pull dense cells (one window of one row, > 4096
 // products) from a ticket, largest first.
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, uint32_t *ticket, RowMeta m,
+__global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
 	constexpr int NW = NT / 64;
@@ -818,20 +857,21 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 	// workgroups are on the same few column windows of B at any time (B's window slice is served
 	// from L2 / Infinity Cache) and every workgroup gets a mix of large and small cells.
 	// Same three-stage software pipeline as k_hash.
-	const uint32_t stride = gridDim.x;
+	const CellWalk walk = cell_walk(xb, ncell);
+	const uint32_t stride = walk.stride, cend = walk.end;
 	Cell rec1{}, rec2{};
-	if (blockIdx.x < ncell) rec1 = cells[blockIdx.x];
-	if (blockIdx.x + stride < ncell) rec2 = cells[blockIdx.x + stride];
+	if (walk.first < cend) rec1 = cells[walk.first];
+	if (walk.first + stride < cend) rec2 = cells[walk.first + stride];
 	uint32_t nlo = 0, nlen = 0; double na = 0;
 	{
 		uint32_t e = rec1.beg + tid;
-		if (blockIdx.x < ncell && e < rec1.end) {
+		if (walk.first < cend && e < rec1.end) {
 			const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1 + rec1.wa;
 			nlo = bw[0]; nlen = bw[1] - nlo;
 			na = m.aval[e];
 		}
 	}
-	for (uint32_t ci = blockIdx.x; ci < ncell; ci += stride) {
+	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
 		const Cell cell = rec1;
 		const uint32_t w = cell.wa;
 		const uint32_t beg = cell.beg, end = cell.end;
@@ -840,9 +880,9 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		const uint32_t wbase = w << WSHIFT;
 		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
 		rec1 = rec2;
-		if (ci + 2 * stride < ncell) rec2 = cells[ci + 2 * stride];
+		if (ci + 2 * stride < cend) rec2 = cells[ci + 2 * stride];
 		int32_t nk = 0; bool nact = false;
-		if (ci + stride < ncell) {
+		if (ci + stride < cend) {
 			uint32_t e = rec1.beg + tid;
 			nact = e < rec1.end;
 			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
@@ -1010,8 +1050,8 @@ static void launch_light(spsamd_ctx *c, const Bins &b, const RowMeta &m, const E
 }
 
 template <int T, int NT, int MODE, bool WINDOWED>
-static void launch_hash(spsamd_ctx *c, const Cell *cells, uint32_t ncell, const RowMeta &m, const uint32_t *bwin, uint32_t nwin1,
-	const EmitParams &ep, const SinkParams &sk)
+static void launch_hash(spsamd_ctx *c, const Cell *cells, uint32_t ncell, const uint32_t *xb, const RowMeta &m, const uint32_t *bwin,
+	uint32_t nwin1, const EmitParams &ep, const SinkParams &sk)
 {
 	if (!ncell) return;
 	static int per_cu = 0;                     // resident workgroups per CU of this instantiation
@@ -1021,7 +1061,8 @@ static void launch_hash(spsamd_ctx *c, const Cell *cells, uint32_t ncell, const 
 		per_cu = nb;
 	}
 	unsigned grid = std::min<unsigned>(ncell, (unsigned)(c->num_cu * per_cu));
-	k_hash<T, NT, MODE, WINDOWED><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, m, bwin, nwin1, ep, sk);
+	if (grid >= 64) grid &= ~7u;               // multiple of 8: the XCD-aware walk
+	k_hash<T, NT, MODE, WINDOWED><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, xb, m, bwin, nwin1, ep, sk);
 	SPS_LAUNCH_CHECK();
 }
 
@@ -1030,9 +1071,9 @@ struct MidCells { Cell *cells[3] = {nullptr, nullptr, nullptr}; };
 template <int MODE>
 static void launch_mid(spsamd_ctx *c, const Bins &b, const MidCells &mc, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
-	launch_hash<1024, 256, MODE, false>(c, mc.cells[0], b.count[5], m, nullptr, 0, ep, sk);
-	launch_hash<4096, 256, MODE, false>(c, mc.cells[1], b.count[6], m, nullptr, 0, ep, sk);
-	launch_hash<8192, 256, MODE, false>(c, mc.cells[2], b.count[7], m, nullptr, 0, ep, sk);
+	launch_hash<1024, 256, MODE, false>(c, mc.cells[0], b.count[5], nullptr, m, nullptr, 0, ep, sk);
+	launch_hash<4096, 256, MODE, false>(c, mc.cells[1], b.count[6], nullptr, m, nullptr, 0, ep, sk);
+	launch_hash<8192, 256, MODE, false>(c, mc.cells[2], b.count[7], nullptr, m, nullptr, 0, ep, sk);
 }
 
 struct Heavy {
@@ -1044,7 +1085,7 @@ struct Heavy {
 	uint32_t ncell[NCLS] = {0, 0, 0, 0};
 	Cell *cells[NCLS] = {nullptr, nullptr, nullptr, nullptr};
 	CellBases cnt{}, base{};
-	uint32_t *ticket = nullptr;
+	uint32_t *xb[NCLS] = {nullptr, nullptr, nullptr, nullptr};   // XCD part boundaries per class
 	int W = 8192;
 	uint32_t cell_cap = CELL_CAP_DEFAULT;
 	unsigned long long clsprod[NCLS] = {0, 0, 0, 0};
@@ -1053,33 +1094,34 @@ struct Heavy {
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
-	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], hv.xb[0], m, hv.bwin, hv.nwin1, ep, sk);
 	static const int hnt = getenv("SPSAMD_HASH_NT") ? atoi(getenv("SPSAMD_HASH_NT")) : 512;
 	if (hnt == 1024) {
-		launch_hash<4096, 1024, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
-		launch_hash<8192, 1024, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<4096, 1024, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<8192, 1024, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
 		return;
 	}
 	if (hnt == 512) {
-		launch_hash<4096, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
-		launch_hash<8192, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<4096, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
+		launch_hash<8192, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
 		return;
 	}
-	launch_hash<4096, 256, MODE, true>(c, hv.cells[1], hv.ncell[1], m, hv.bwin, hv.nwin1, ep, sk);
-	launch_hash<8192, 256, MODE, true>(c, hv.cells[2], hv.ncell[2], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<4096, 256, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<8192, 256, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
 }
 
 template <int MODE>
 static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	if (!hv.ncell[3]) return;
-	fill_zero(c, hv.ticket, sizeof(uint32_t));
 	if (hv.W == 8192) {
 		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu * 2u);
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
+		if (grid >= 64) grid &= ~7u;
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.xb[3], m, hv.bwin, hv.nwin1, ep, sk);
 	} else {
 		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu);
-		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.ticket, m, hv.bwin, hv.nwin1, ep, sk);
+		if (grid >= 64) grid &= ~7u;
+		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.xb[3], m, hv.bwin, hv.nwin1, ep, sk);
 	}
 	SPS_LAUNCH_CHECK();
 }
@@ -1123,7 +1165,6 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
-	hv.ticket = c->arena.get<uint32_t>(1);
 }
 
 // Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.
@@ -1146,6 +1187,22 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 		k_gather_cells<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], where ? p1 : p0, nd, sorted);
 		SPS_LAUNCH_CHECK();
 		hv.cells[k] = sorted;
+	}
+	// Measured on R-MAT scale-20: giving each XCD its own part of the list is SLOWER (dense 80 vs
+	// 57 ms, hash 73 vs 62 ms) than letting all XCDs walk the same windows together, so the
+	// partition stays an experiment behind SPSAMD_XCD=1.
+	static const bool xcd_aware = getenv("SPSAMD_XCD") && atoi(getenv("SPSAMD_XCD"));
+	for (int k = 0; k < NCLS && xcd_aware; ++k) {
+		uint32_t nd = hv.ncell[k];
+		if (nd < 4096) continue;
+		uint32_t *cost = c->arena.get<uint32_t>(nd);
+		int64_t *pref = c->arena.get<int64_t>((size_t)nd + 1);
+		k_cell_cost<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == 3 ? 6000u : 2000u, cost);
+		SPS_LAUNCH_CHECK();
+		scan_exclusive_u32_i64(c, cost, pref, nd);
+		hv.xb[k] = c->arena.get<uint32_t>(9);
+		k_xcd_bounds<<<dim3(1), dim3(64), 0, st>>>(pref, nd, hv.xb[k]);
+		SPS_LAUNCH_CHECK();
 	}
 }
 
