@@ -178,13 +178,32 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        # dominant kernel of rank 0: the dense-window kernel of the heavy rows
-        # (k_heavy), timed with HIP events on the library's stream in every step
-        classes = [("k_heavy", "heavy"), ("k_mid", "mid"), ("k_light", "light")]
-        name, cls = max(classes, key=lambda c: getattr(res, "products_" + c[1]))
-        ms_kernel = sum(getattr(r[0], "ms_" + cls) for r in results) / len(results)
-        alg_bytes = 16 * getattr(res, "tuples_" + cls) + 12 * getattr(res, "products_" + cls)
+        # dominant kernel of rank 0 = the numeric kernel with the largest duration, timed with HIP
+        # events on the library's stream in every step.  Algorithmic bytes of one launch =
+        # 12 B per scalar product it processes + 16 B per A tuple of its rows.
+        def avg(f):
+            return sum(f(r[0]) for r in results) / len(results)
+        p_hash = res.products_heavy - res.products_dense
+        t_heavy = max(1, res.products_heavy)
+        kernels = [
+            ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, res.tuples_heavy * res.products_dense / t_heavy),
+            ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense), p_hash, res.tuples_heavy * p_hash / t_heavy),
+            ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
+            ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
+        ]
+        name, ms_kernel, k_prod, k_tup = max(kernels, key=lambda k: k[1])
+        alg_bytes = int(16 * k_tup + 12 * k_prod)
         achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (bench.py cannot run the profiler on itself); null when no pass covers the kernel
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if scale == 20 and world == 1 and name in pmc["kernels"]:
+                traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "nnz(C)/s for C=A*A SpGEMM",
             "value": nnz_c * args.steps / elapsed,
@@ -208,10 +227,13 @@ def main():
                 "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,
                 "products_per_s": products / (ms_step * 1e-3),
                 "stage_ms_rank0": {"consolidate": res.ms_consolidate, "symbolic": res.ms_symbolic, "numeric": res.ms_numeric,
-                                   "light": res.ms_light, "mid": res.ms_mid, "heavy": res.ms_heavy},
+                                   "light": res.ms_light, "mid": res.ms_mid, "heavy_hash_cells": res.ms_heavy - res.ms_dense,
+                                   "heavy_dense_cells": res.ms_dense},
+                "rows_rank0": {"light": res.rows_light, "mid": res.rows_mid, "heavy": res.rows_heavy,
+                               "hash_cells": res.cells_hash, "dense_cells": res.cells_dense},
             },
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel},
         }
         if world == 1 and not args.no_cpu_baseline:
