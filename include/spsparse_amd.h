@@ -155,6 +155,21 @@ int spsamd_multiply(spsamd_ctx *ctx, double C,
 	spsamd_result *result);
 
 /*
+ * ret = C * diag(scalei) * op(A) * diag(scalej) * V
+ * -- spsparse::multiply, matrix x sparse vector (multiply_sparse.hpp:281-365).
+ * V is consolidated with sort order {0} (:313).  The result is rank 1:
+ * result->idx0 holds the row indices, idx1 is all zero, shape1 is 0.
+ */
+int spsamd_multiply_mv(spsamd_ctx *ctx, double C,
+	const spsamd_vec *scalei,
+	const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej,
+	const spsamd_vec *V,
+	int duplicate_policy, int zero_nan,
+	int sink_kind, int sink_flags,
+	spsamd_result *result);
+
+/*
  * Host delivery of the last SINK_COO result of ctx: calls cb(user, i, j, v, n)
  * with consecutive chunks (host pointers, valid during the call) in ascending
  * (i, j) order -- the shim's callback loops ret.add({i,j}, v)

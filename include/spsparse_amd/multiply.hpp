@@ -252,6 +252,56 @@ void multiply(
 	if (rc != 0) (*spsparse_error)(-1, "%s", spsamd_last_error(ctx));
 }
 
+template <class AccumulatorT>
+int add_chunk_v(void *user, const int32_t *i, const int32_t *, const double *v, size_t n);
+
+// ---- multiply, matrix x sparse vector: multiply_sparse.hpp:281-365 --------
+template <class ScaleIT, class MatAT, class ScaleJT, class VecT, class AccumulatorT>
+void multiply(
+	AccumulatorT &ret,
+	double C,                // Multiply everything by this
+	ScaleIT const *scalei,
+	MatAT const &A,
+	char transpose_A,        // 'T' for transpose, '.' otherwise
+	ScaleJT const *scalej,
+	VecT const &V,
+	DuplicatePolicy duplicate_policy = DuplicatePolicy::ADD,
+	bool zero_nan = false)
+{
+	static_assert(VecT::rank == 1, "the right operand of the matrix-vector multiply has rank 1");
+	std::array<int, 2> const &a_sort_order(transpose_A == 'T' ? COL_MAJOR : ROW_MAJOR);
+	ret.set_shape({A.shape[a_sort_order[0]]});                       // :295
+	if (A.shape[a_sort_order[1]] != V.shape[0]) {                    // :298-300
+		(*spsparse_error)(-1, "Inner dimensions for A (%ld) and V (%ld) must match!",
+			(long)A.shape[a_sort_order[1]], (long)V.shape[0]);
+		return;
+	}
+	if ((C == 0) || (scalei && scalei->size() == 0) || (A.size() == 0)
+		|| (scalej && scalej->size() == 0) || (V.size() == 0))       // :304-309
+	{ return; }
+
+	spsamd_coo a = detail::as_coo(A);
+	spsamd_vec v = detail::as_vec(V), si, sj;
+	if (scalei) si = detail::as_vec(*scalei);
+	if (scalej) sj = detail::as_vec(*scalej);
+	spsamd_ctx *ctx = default_context().get();
+	if (!ctx) return;
+	spsamd_result res;
+	int rc = spsamd_multiply_mv(ctx, C, scalei ? &si : nullptr, &a, transpose_A, scalej ? &sj : nullptr, &v,
+		(int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, 0, &res);
+	if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
+	rc = spsamd_result_fetch(ctx, &res, &add_chunk_v<AccumulatorT>, &ret);
+	if (rc != 0) (*spsparse_error)(-1, "%s", spsamd_last_error(ctx));
+}
+
+template <class AccumulatorT>
+int add_chunk_v(void *user, const int32_t *i, const int32_t *, const double *v, size_t n)
+{
+	AccumulatorT &ret = *static_cast<AccumulatorT *>(user);
+	for (size_t q = 0; q < n; ++q) ret.add({i[q]}, v[q]);            // multiply_sparse.hpp:360
+	return 0;
+}
+
 // ---- VectorCooArray::consolidate on the device ---------------------------
 template <class IndexT, class ValT, int RANK>
 void VectorCooArray<IndexT, ValT, RANK>::consolidate(std::array<int, RANK> const &_sort_order,

@@ -57,7 +57,7 @@ CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_
 
 # every symbol include/spsparse_amd.h declares
 SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
-           "spsamd_multiply", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_gen_rmat",
+           "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
 
 _lib = None
@@ -91,6 +91,8 @@ def load():
     L.spsamd_version.restype = C.c_char_p
     L.spsamd_multiply.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Coo), C.c_char, P(Vec),
                                   C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
+    L.spsamd_multiply_mv.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Vec),
+                                     C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_result_fetch.argtypes = [C.c_void_p, P(Result), CHUNK_FN, C.c_void_p]
     L.spsamd_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.spsamd_consolidate.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_int, C.c_int, P(Result)]
@@ -159,6 +161,16 @@ class Context:
         ptr = [None if s is None else C.byref(s) for s in (scalei, scalej, scalek)]
         rc = self.L.spsamd_multiply(self.h, float(C_), ptr[0], C.byref(A), tA.encode(), ptr[1], C.byref(B),
                                     tB.encode(), ptr[2], duplicate_policy, int(zero_nan), sink, flags, C.byref(res))
+        self._check(rc)
+        return res
+
+    def multiply_mv(self, A, V, C_=1.0, scalei=None, tA='.', scalej=None, duplicate_policy=ADD, zero_nan=False,
+                    sink=SINK_COO, flags=0):
+        """spsamd_multiply_mv.  A: Coo struct; V, scale*: Vec structs."""
+        res = Result()
+        ptr = [None if s is None else C.byref(s) for s in (scalei, scalej)]
+        rc = self.L.spsamd_multiply_mv(self.h, float(C_), ptr[0], C.byref(A), tA.encode(), ptr[1], C.byref(V),
+                                       duplicate_policy, int(zero_nan), sink, flags, C.byref(res))
         self._check(rc)
         return res
 

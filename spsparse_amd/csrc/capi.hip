@@ -79,6 +79,55 @@ static bool same_operand(const spsamd_coo *a, const spsamd_coo *b)
 		a->shape0 == b->shape0 && a->shape1 == b->shape1 && a->sort0 == b->sort0 && a->mem == b->mem;
 }
 
+// Shared body of the MM and MV entry points.  `what` names the right operand in
+// the inner-dimension message ("B" or "V", multiply_sparse.hpp:173,299).
+static int multiply_body(spsamd_ctx *c, double C,
+	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
+	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,
+	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready)
+{
+	if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+	if (sink_kind != SPSAMD_SINK_COO && sink_kind != SPSAMD_SINK_DIGEST) throw Error{SPSAMD_EINVAL, "bad sink_kind"};
+	std::memset(res, 0, sizeof(*res));
+	// multiply_sparse.hpp:167-169: op(A) rows = A.shape[a0]; op(B) is read by ROWS here
+	// (inner index first), its columns are B.shape[bj]
+	const int a0 = transpose_A == 'T' ? 1 : 0, a1 = 1 - a0;
+	const int bk = transpose_B == 'T' ? 1 : 0, bj = 1 - bk;
+	const size_t ashape[2] = {A->shape0, A->shape1}, bshape[2] = {B->shape0, B->shape1};
+	res->shape0 = ashape[a0];
+	res->shape1 = bshape[bj];
+	if (ashape[a1] != bshape[bk]) {                                  // :172-174
+		char buf[160];
+		std::snprintf(buf, sizeof buf, "Inner dimensions for A (%ld) and %s (%ld) must match!", (long)ashape[a1], what, (long)bshape[bk]);
+		throw Error{SPSAMD_EDIM, buf};
+	}
+	if (C == 0 || (scalei && scalei->nnz == 0) || A->nnz == 0 || (scalej && scalej->nnz == 0) ||
+		B->nnz == 0 || (scalek && scalek->nnz == 0))                 // :178-184
+		return SPSAMD_OK;
+
+	SPS_HIP(hipSetDevice(c->device));
+	if (!arena_ready) c->arena.reset();
+	hipStream_t st = c->stream;
+	SPS_HIP(hipEventRecord(c->ev[0], st));
+	MultiplyArgs a;
+	a.C = C; a.sink_kind = sink_kind; a.sink_flags = sink_flags;
+	consolidate_operand(c, A, a0, duplicate_policy, zero_nan, &a.A);          // :187
+	if (a0 == bk && same_operand(A, B)) a.B = a.A;                             // A*A: one consolidation serves both
+	else consolidate_operand(c, B, bk, duplicate_policy, zero_nan, &a.B);      // :188
+	upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
+	upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
+	upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
+	spgemm(c, a, res);
+	SPS_HIP(hipEventRecord(c->ev[7], st));
+	SPS_HIP(hipEventSynchronize(c->ev[7]));
+	if (res->nnz_a && res->nnz_b) {
+		SPS_HIP(hipEventElapsedTime(&res->ms_consolidate, c->ev[0], c->ev[1]));
+	}
+	SPS_HIP(hipEventElapsedTime(&res->ms_total, c->ev[0], c->ev[7]));
+	return SPSAMD_OK;
+}
+
 extern "C" int spsamd_multiply(spsamd_ctx *c, double C,
 	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
 	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
@@ -88,45 +137,43 @@ extern "C" int spsamd_multiply(spsamd_ctx *c, double C,
 	if (!c) return SPSAMD_EINVAL;
 	API_GUARD(c,
 		if (!A || !B || !res) throw Error{SPSAMD_EINVAL, "null operand or result"};
-		if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
-		if (sink_kind != SPSAMD_SINK_COO && sink_kind != SPSAMD_SINK_DIGEST) throw Error{SPSAMD_EINVAL, "bad sink_kind"};
-		std::memset(res, 0, sizeof(*res));
-		// multiply_sparse.hpp:167-169: op(A) rows = A.shape[a0]; op(B) is read by ROWS here
-		// (inner index first), its columns are B.shape[bj]
-		const int a0 = transpose_A == 'T' ? 1 : 0, a1 = 1 - a0;
-		const int bk = transpose_B == 'T' ? 1 : 0, bj = 1 - bk;
-		const size_t ashape[2] = {A->shape0, A->shape1}, bshape[2] = {B->shape0, B->shape1};
-		res->shape0 = ashape[a0];
-		res->shape1 = bshape[bj];
-		if (ashape[a1] != bshape[bk]) {                                  // :172-174
-			char buf[160];
-			std::snprintf(buf, sizeof buf, "Inner dimensions for A (%ld) and B (%ld) must match!", (long)ashape[a1], (long)bshape[bk]);
-			throw Error{SPSAMD_EDIM, buf};
-		}
-		if (C == 0 || (scalei && scalei->nnz == 0) || A->nnz == 0 || (scalej && scalej->nnz == 0) ||
-			B->nnz == 0 || (scalek && scalek->nnz == 0))                 // :178-184
-			return SPSAMD_OK;
+		return multiply_body(c, C, scalei, A, transpose_A, scalej, B, transpose_B, scalek, duplicate_policy, zero_nan,
+			sink_kind, sink_flags, res, "B", false);
+	)
+}
 
+// Matrix x sparse vector (multiply_sparse.hpp:281-365): V is the one-column
+// matrix (idx, 0) of shape (V.shape0, 1); consolidating it row-major is
+// Consolidate<VecT>(&V, {0}) (:313).  The result's idx1 is all zero.
+extern "C" int spsamd_multiply_mv(spsamd_ctx *c, double C,
+	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej, const spsamd_vec *V,
+	int duplicate_policy, int zero_nan, int sink_kind, int sink_flags, spsamd_result *res)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!A || !V || !res) throw Error{SPSAMD_EINVAL, "null operand or result"};
 		SPS_HIP(hipSetDevice(c->device));
 		c->arena.reset();
-		hipStream_t st = c->stream;
-		SPS_HIP(hipEventRecord(c->ev[0], st));
-		MultiplyArgs a;
-		a.C = C; a.sink_kind = sink_kind; a.sink_flags = sink_flags;
-		consolidate_operand(c, A, a0, duplicate_policy, zero_nan, &a.A);          // :187
-		if (a0 == bk && same_operand(A, B)) a.B = a.A;                             // A*A: one consolidation serves both
-		else consolidate_operand(c, B, bk, duplicate_policy, zero_nan, &a.B);      // :188
-		upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
-		upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
-		upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
-		spgemm(c, a, res);
-		SPS_HIP(hipEventRecord(c->ev[7], st));
-		SPS_HIP(hipEventSynchronize(c->ev[7]));
-		if (res->nnz_a && res->nnz_b) {
-			SPS_HIP(hipEventElapsedTime(&res->ms_consolidate, c->ev[0], c->ev[1]));
+		spsamd_coo Vm;
+		Vm.nnz = V->nnz; Vm.shape0 = V->shape0; Vm.shape1 = 1;
+		Vm.sort0 = V->sort0 == 0 ? 0 : -1;
+		Vm.mem = SPSAMD_MEM_DEVICE;
+		Vm.idx0 = nullptr; Vm.idx1 = nullptr; Vm.val = nullptr;
+		if (V->nnz) {
+			if (!V->idx || !V->val) throw Error{SPSAMD_EINVAL, "vector with nnz > 0 has a null array"};
+			int32_t *vi = c->arena.get<int32_t>(V->nnz), *vz = c->arena.get<int32_t>(V->nnz);
+			double *vv = c->arena.get<double>(V->nnz);
+			hipMemcpyKind kind = V->mem == SPSAMD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+			SPS_HIP(hipMemcpyAsync(vi, V->idx, V->nnz * sizeof(int32_t), kind, c->stream));
+			SPS_HIP(hipMemcpyAsync(vv, V->val, V->nnz * sizeof(double), kind, c->stream));
+			fill_zero(c, vz, V->nnz * sizeof(int32_t));
+			Vm.idx0 = vi; Vm.idx1 = vz; Vm.val = vv;
 		}
-		SPS_HIP(hipEventElapsedTime(&res->ms_total, c->ev[0], c->ev[7]));
-		return SPSAMD_OK;
+		int rc = multiply_body(c, C, scalei, A, transpose_A, scalej, &Vm, '.', nullptr, duplicate_policy, zero_nan,
+			sink_kind, sink_flags, res, "V", true);
+		res->shape1 = 0;                              // rank-1 result: ret.set_shape({rows}) (:295)
+		return rc;
 	)
 }
 

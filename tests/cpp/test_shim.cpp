@@ -90,6 +90,36 @@ static void test_random_MM_multiply(unsigned int dsize, int seed, long *ntuples)
 	*ntuples += (long)C.size();
 }
 
+// tests/test_multiply_sparse.cpp:138-196
+static void test_random_MV_multiply(unsigned int dsize, int seed, long *ntuples)
+{
+	std::default_random_engine generator(seed);
+	auto dim_distro(std::bind(std::uniform_int_distribution<int>(0, dsize - 1), generator));
+	auto val_distro(std::bind(std::uniform_real_distribution<double>(0, 1), generator));
+
+	Mat A({dsize, dsize});
+	Vec B({dsize});
+	int nranda = (int)(val_distro() * (double)(dsize * dsize));
+	for (int i = 0; i < nranda; ++i) { int r = dim_distro(); int c = dim_distro(); A.add({r, c}, val_distro()); }
+	int nrandb = (int)(val_distro() * (double)dsize);
+	for (int i = 0; i < nrandb; ++i) { int r = dim_distro(); B.add({r}, val_distro()); }
+
+	Vec C;
+	multiply(C, 1.0, (Vec *)0, A, '.', (Vec *)0, B);
+
+	auto Ad(to_dense(A));
+	std::vector<double> Bd(dsize, 0.0), Cd(dsize, 0.0);
+	for (size_t q = 0; q < B.size(); ++q) Bd[B.index(0, q)] += B.val(q);
+	for (size_t q = 0; q < C.size(); ++q) Cd[C.index(0, q)] += C.val(q);
+	CHECK(C.shape[0] == dsize);
+	for (unsigned i = 0; i < dsize; ++i) {
+		double sum = 0;
+		for (unsigned k = 0; k < dsize; ++k) sum += Ad[i * dsize + k] * Bd[k];
+		if (sum != Cd[i]) { std::printf("MV seed %d (%u): %g vs %g\n", seed, i, sum, Cd[i]); ++failures; }   // exact, as :183
+	}
+	*ntuples += (long)C.size();
+}
+
 // tests/test_array.cpp:135-168 through the device consolidate
 static void test_consolidate()
 {
@@ -169,6 +199,10 @@ int main(int argc, char **argv)
 	for (int seed = 1; seed < 1000; ++seed) test_random_MM_multiply(5, seed, &ntuples);
 	std::printf("random_MM_multiply: 999 seeds, %ld tuples\n", ntuples);
 	CHECK(ntuples > 5000);
+	long nv = 0;
+	for (int seed = 1; seed < 1000; ++seed) test_random_MV_multiply(5, seed, &nv);
+	std::printf("random_MV_multiply: 999 seeds, %ld tuples\n", nv);
+	CHECK(nv > 500);
 	test_consolidate();
 	test_errors_and_append();
 	std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);

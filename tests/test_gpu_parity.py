@@ -97,6 +97,66 @@ def test_random_mm_property(ctx):
     assert total > 5000
 
 
+def _dev_mv(ctx, A, V, **kw):
+    from spsparse_amd import capi
+    a, k1 = capi.host_coo(A.idx0, A.idx1, A.val, A.shape, A.sort0)
+    v, k2 = capi.host_vec(V.idx, V.val, V.shape0, V.sort0)
+    keep = [k1, k2]
+
+    def vec(S):
+        if S is None:
+            return None
+        s, k = capi.host_vec(S.idx, S.val, S.shape0)
+        keep.append(k)
+        return s
+
+    res = ctx.multiply_mv(a, v, kw.get("C_", 1.0), vec(kw.get("scalei")), kw.get("tA", "."), vec(kw.get("scalej")),
+                          kw.get("duplicate_policy", capi.ADD), kw.get("zero_nan", False))
+    i, j, val = ctx.fetch(res)
+    assert not j.any()
+    return i, val, res
+
+
+def test_random_mv_property(ctx):
+    """tests/test_multiply_sparse.cpp:138-203 through spsamd_multiply_mv: 999 seeded 5x5 cases,
+    exact equality like the reference's `sum != Cd(i)` check."""
+    from tests.test_oracle_pins import RANDOM5
+    _, mv = RANDOM5
+    total = 0
+    for seed, ((ai, av), (vi, vv)) in mv:
+        A = orc.Mat(ai[0], ai[1], av, (5, 5))
+        V = orc.Vec(vi[0], vv, 5)
+        wi, _, wv, wshape = orc.multiply_mv(A, V)
+        gi, gv, res = _dev_mv(ctx, A, V)
+        assert (res.shape0, res.shape1) == (5, 0)
+        assert np.array_equal(gi, wi) and np.array_equal(gv, wv), seed
+        total += len(wv)
+    assert total > 500
+
+
+def test_mv_flags_scales(ctx):
+    """MV with 'T', scalei/scalej, C != 1 and duplicate policies against the oracle; error text for V."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(9)
+    for trial in range(16):
+        m, k = rng.integers(1, 80, 2)
+        tA = "T" if trial % 2 else "."
+        A = _rand_mat(rng, (k, m) if tA == "T" else (m, k), int(rng.integers(1, 900)), zeros=True)
+        nv = int(rng.integers(1, 2 * k + 1))
+        V = orc.Vec(rng.integers(0, k, nv), rng.uniform(0.1, 1, nv), k)
+        kw = dict(C_=3.0, tA=tA, scalei=_rand_vec(rng, m) if trial % 3 == 0 else None,
+                  scalej=_rand_vec(rng, k) if trial % 3 == 1 else None,
+                  duplicate_policy=[orc.ADD, orc.LEAVE_ALONE, orc.REPLACE][trial % 3])
+        wi, _, wv, wshape = orc.multiply_mv(A, V, **kw)
+        gi, gv, res = _dev_mv(ctx, A, V, **kw)
+        assert res.shape0 == wshape[0]
+        assert np.array_equal(gi, wi)
+        if len(wv):
+            assert np.max(np.abs(gv - wv) / np.abs(wv)) <= REL
+    with pytest.raises(capi.SpsamdError, match=r"Inner dimensions for A \(3\) and V \(4\) must match!"):
+        _dev_mv(ctx, orc.Mat([0], [1], [2.], (2, 3)), orc.Vec([0], [1.], 4))
+
+
 def _rand_mat(rng, shape, nnz, zeros=False, positive=True):
     i0 = rng.integers(0, shape[0], nnz)
     i1 = rng.integers(0, shape[1], nnz)
