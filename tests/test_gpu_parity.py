@@ -411,3 +411,100 @@ def test_device_resident_operands_rmat15(ctx):
     # the COO sink on the same operands: sorted, same count
     r = ctx.multiply(Ad, Ad, sink=capi.SINK_COO)
     assert r.nnz == cnt
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: too large for a tuple-by-tuple oracle, checked through
+# size-independent properties (linearity: C 1 = A (B 1); closed-form sizes of the stencils;
+# agreement of the two sinks).
+
+def _device_operand(ctx, gen, n_tuples, shape, sort0=-1):
+    import torch
+    from spsparse_amd import capi
+    dev = torch.device("cuda:0")
+    t = (torch.empty(n_tuples, dtype=torch.int32, device=dev), torch.empty(n_tuples, dtype=torch.int32, device=dev),
+         torch.empty(n_tuples, dtype=torch.float64, device=dev))
+    gen(*[x.data_ptr() for x in t])
+    torch.cuda.synchronize()
+    return capi.device_coo(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n_tuples, shape, sort0), t
+
+
+def _row_sums_by_linearity(a, b, n_rows, n_inner):
+    """(A B) 1 = A (B 1): per-row sums of C from O(nnz) host arithmetic."""
+    b1 = np.bincount(b[0], weights=b[2], minlength=n_inner)
+    return np.bincount(a[0], weights=a[2] * b1[a[1]], minlength=n_rows)
+
+
+def test_cfg2_rmat20_full_size_properties(ctx):
+    """BASELINE cfg2: R-MAT scale-20 A*A (P = 2.09e10, nnz(C) = 9.7e9) -- every row sum and the
+    grand sum follow from linearity; nnz(C) is bounded by the products and reproducible."""
+    from spsparse_amd import capi
+    scale, seed = 20, 1
+    n, ne = 1 << scale, 16 << scale
+    A, keep = _device_operand(ctx, lambda *p: ctx.gen_rmat(scale, seed, 0, ne, *p), ne, (n, n))
+    d = ctx.multiply(A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    a = wl.rmat(scale, seed)
+    want = _row_sums_by_linearity(a, a, n, n)
+    got = ctx.to_host(d.row_sum, n, np.float64)
+    nz = want != 0
+    assert np.array_equal(got != 0, nz)                  # values are positive: a row is empty iff its sum is 0
+    assert np.max(np.abs(got[nz] - want[nz]) / want[nz]) <= 1e-10
+    assert abs(d.sum - want.sum()) <= 1e-10 * want.sum()
+    rn = ctx.to_host(d.row_nnz, n, np.int64)
+    assert int(rn.sum()) == d.nnz and 9.0e9 < d.nnz < 1.1e10 and d.nnz <= d.products
+    assert d.products == 20924218068 and d.nnz_a == 16086131
+    d2 = ctx.multiply(A, A, sink=capi.SINK_DIGEST)
+    assert (d2.nnz, d2.hash) == (d.nnz, d.hash)          # index set independent of the atomics' order
+
+
+def test_cfg3_poisson4096_full_size_properties(ctx):
+    """BASELINE cfg3: 5-point Poisson on a 4096^2 grid, A*A, both sinks; closed forms."""
+    from spsparse_amd import capi
+    N = 4096
+    na = 5 * N * N - 4 * N
+    A, keep = _device_operand(ctx, lambda *p: ctx.gen_poisson2d(N, *p), na, (N * N, N * N), sort0=0)
+    d = ctx.multiply(A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    assert d.products == 25 * N * N - 36 * N + 8 and d.nnz == 13 * N * N - 20 * N + 4
+    # row sums of A are 0 in the interior: (A A) 1 = A (A 1) is exact in integers
+    i = np.arange(N * N)
+    y, x = i // N, i % N
+    a1 = 4.0 - (y > 0) - (y < N - 1) - (x > 0) - (x < N - 1)
+    up = np.where(y > 0, np.roll(a1, N), 0.0)
+    dn = np.where(y < N - 1, np.roll(a1, -N), 0.0)
+    lf = np.where(x > 0, np.roll(a1, 1), 0.0)
+    rt = np.where(x < N - 1, np.roll(a1, -1), 0.0)
+    want = 4.0 * a1 - up - dn - lf - rt
+    got = ctx.to_host(d.row_sum, N * N, np.float64)
+    assert np.array_equal(got, want)
+    r = ctx.multiply(A, A, sink=capi.SINK_COO)
+    assert r.nnz == d.nnz
+    # spot-check the COO result's first and last rows on the host
+    head = ctx.to_host(r.val, 3, np.float64)
+    assert head.tolist() == [18.0, -8.0, 1.0]
+
+
+def test_cfg5_galerkin256_full_size_properties(ctx):
+    """BASELINE cfg5: R*A*R^T on the 256^3 Laplacian; closed forms nnz(T)=32nc^3-24nc^2,
+    nnz(C)=7nc^3-6nc^2 and the value set {24,-4} (every entry an integer: exact)."""
+    import torch
+    from spsparse_amd import capi
+    N, nc = 256, 128
+    A, k1 = _device_operand(ctx, lambda *p: ctx.gen_laplace3d(N, *p), 7 * N ** 3 - 6 * N ** 2, (N ** 3, N ** 3), sort0=0)
+    R, k2 = _device_operand(ctx, lambda *p: ctx.gen_aggregation3d(N, *p), N ** 3, (nc ** 3, N ** 3), sort0=0)
+    rt = ctx.multiply(R, A, sink=capi.SINK_COO)
+    nt = int(rt.nnz)
+    assert nt == 32 * nc ** 3 - 24 * nc ** 2 and rt.products == 7 * N ** 3 - 6 * N ** 2
+    dev = torch.device("cuda:0")
+    t = (torch.empty(nt, dtype=torch.int32, device=dev), torch.empty(nt, dtype=torch.int32, device=dev),
+         torch.empty(nt, dtype=torch.float64, device=dev))
+    ctx.memcpy(t[0].data_ptr(), rt.idx0, nt * 4)
+    ctx.memcpy(t[1].data_ptr(), rt.idx1, nt * 4)
+    ctx.memcpy(t[2].data_ptr(), rt.val, nt * 8)
+    T = capi.device_coo(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), nt, (nc ** 3, N ** 3), sort0=0)
+    rc = ctx.multiply(T, R, tB="T", sink=capi.SINK_COO)
+    assert rc.nnz == 7 * nc ** 3 - 6 * nc ** 2 and rc.products == nt
+    vals = np.unique(ctx.to_host(rc.val, int(rc.nnz), np.float64))
+    assert vals.tolist() == [-4.0, 24.0]
+    ci = ctx.to_host(rc.idx0, int(rc.nnz), np.int32).astype(np.int64)
+    cj = ctx.to_host(rc.idx1, int(rc.nnz), np.int32)
+    assert np.all(np.diff(ci * nc ** 3 + cj) > 0)         # ascending (i, j), each once
