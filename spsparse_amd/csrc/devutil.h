@@ -10,7 +10,7 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Inclusive scan across the 64 lanes of a wave.
+// Inclusive scan across the 64 lanes of a wave (generic: LDS-crossbar shuffles).
 template <class T>
 __device__ __forceinline__ T wave_inclusive_scan(T v)
 {
@@ -20,6 +20,20 @@ __device__ __forceinline__ T wave_inclusive_scan(T v)
 		if ((int)lane_id() >= d) v += o;
 	}
 	return v;
+}
+
+// uint32 inclusive scan with DPP row shifts and row broadcasts (gfx9 family): six
+// VALU adds instead of six dependent ds_bpermute round trips.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);      // row_bcast:15 -> rows 1 and 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);      // row_bcast:31 -> rows 2 and 3
+	return (uint32_t)x;
 }
 
 template <class T>

@@ -63,6 +63,8 @@ struct RowMeta {
 	const uint32_t *bptr;           // B dense row pointer
 	const int32_t *bcol;
 	const double *bval;
+	const uint32_t *elo;            // A tuples: first B tuple of the selected row (bptr[k])
+	const uint32_t *elen;           // A tuples: length of the selected B row
 };
 
 __device__ __forceinline__ double row_scale(const EmitParams &p, int32_t rowid)
@@ -120,10 +122,10 @@ __device__ __forceinline__ void digest_flush(DigestSlot *slots, unsigned long lo
 
 // ====================================================================== symbolic
 
-__global__ void k_elem_len(const int32_t *acol, const uint32_t *bptr, uint32_t n, uint32_t *len)
+__global__ void k_elem_len(const int32_t *acol, const uint32_t *bptr, uint32_t n, uint32_t *lo, uint32_t *len)
 {
 	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e < n) { int32_t k = acol[e]; len[e] = bptr[k + 1] - bptr[k]; }
+	if (e < n) { int32_t k = acol[e]; uint32_t b = bptr[k]; lo[e] = b; len[e] = bptr[k + 1] - b; }
 }
 
 // scalej (multiply_sparse.hpp:221-228): a k absent from the vector drops the
@@ -211,6 +213,10 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *rbin, uint32
 
 // ====================================================================== light rows
 
+// LDS traffic of ONE wave is ordered by the hardware; waiting for its completion makes a
+// wave's stores visible to its other lanes without a workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // One wave handles G = 64/S rows, S product slots each.
 template <int S, int MODE>
 __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t nbin, RowMeta m, EmitParams ep, SinkParams sk)
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t
 		uint32_t e = beg + base + s;
 		bool act = has_row && e < end;
 		uint32_t lo = 0, len = 0;
-		if (act) { int32_t k = m.acol[e]; lo = m.bptr[k]; len = m.bptr[k + 1] - lo; }
+		if (act) { lo = m.elo[e]; len = m.elen[e]; }
 		uint32_t inc = len;
 #pragma unroll
 		for (int d = 1; d < S; d <<= 1) {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t
 		off += (uint32_t)__shfl((int)inc, (int)(g * S + S - 1), 64);
 	}
 	s_key2[w][lane] = ~0ull;
-	__syncthreads();
+	wave_lds_sync();                // the LDS arrays are per wave: no workgroup barrier needed
 
 	// ---- product + key (col, A position): ascending A position = ascending k
 	const bool act = has_row && s < off;
@@ -268,13 +274,13 @@ __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t
 		key = ((uint64_t)(uint32_t)m.bcol[bp] << 32) | (uint64_t)ap;
 	}
 	s_key[w][lane] = key;
-	__syncthreads();
+	wave_lds_sync();
 	// ---- rank inside the row's S slots (keys are unique), scatter to sorted order
 	uint32_t rank = 0;
 #pragma unroll 8
 	for (int j = 0; j < S; ++j) rank += (s_key[w][g * S + j] < key) ? 1u : 0u;
 	if (act) { s_key2[w][g * S + rank] = key; s_val2[w][g * S + rank] = prod; }
-	__syncthreads();
+	wave_lds_sync();
 
 	// ---- segmented sum in ascending k (sequential, like `sum += a*b`)
 	const uint64_t mykey = s_key2[w][lane];
@@ -377,7 +383,7 @@ __device__ __forceinline__ void expand_load(Expand<NT, PB> &L, uint32_t lo, uint
 	uint32_t &flip)
 {
 	constexpr int NW = NT / 64;
-	const uint32_t inc = wave_inclusive_scan(len);
+	const uint32_t inc = wave_inclusive_scan_u32(len);
 	const uint64_t nzm = __ballot(len != 0);
 	const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
 	if (lane_id() == 63) L.scrL[flip][wave_id()] = inc;
@@ -1232,8 +1238,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 
 	// ---- symbolic: products per A tuple, per row, bins
 	uint32_t *elen = c->arena.get<uint32_t>(A.nnz);
+	uint32_t *elo = c->arena.get<uint32_t>(A.nnz);
 	int64_t *pref = c->arena.get<int64_t>((size_t)A.nnz + 1);
-	k_elem_len<<<dim3(grid_for(A.nnz)), dim3(256), 0, st>>>(acol, bptr, A.nnz, elen);
+	k_elem_len<<<dim3(grid_for(A.nnz)), dim3(256), 0, st>>>(acol, bptr, A.nnz, elo, elen);
 	SPS_LAUNCH_CHECK();
 	scan_exclusive_u32_i64(c, elen, pref, A.nnz);
 	uint32_t *rprod = c->arena.get<uint32_t>(rl.nrows);
@@ -1273,7 +1280,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->tuples_mid = hbc.tuples[5] + hbc.tuples[6] + hbc.tuples[7];
 	res->tuples_heavy = hbc.tuples[8];
 
-	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val};
+	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
 		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0};
 
