@@ -498,7 +498,7 @@ template <int T, int NT, int MODE, bool WINDOWED>
 __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
-	constexpr int LOGT = T == 1024 ? 10 : (T == 4096 ? 12 : 13);
+	constexpr int LOGT = T == 1024 ? 10 : (T == 2048 ? 11 : (T == 4096 ? 12 : 13));   // power-of-two T only
 	__shared__ int32_t h_key[T];
 	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
 	__shared__ uint16_t occ[T / 2];
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			nact = e < rec1.end;
 			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
 		}
+		if (cell.prods > (uint32_t)(T / 2)) continue;               // never: the class bounds the cell (guards the LDS tables)
 		lds_barrier();                                              // previous cell fully emitted, its s_nocc read
 		if (tid == 0) s_nocc = 0;
 
@@ -585,12 +586,14 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 					bool isnew = false;
 					uint32_t h = 0;
 					if (ok[u]) {
-						h = ((uint32_t)col[u] * 0x9E3779B1u) >> (32 - LOGT);
+						if constexpr ((T & (T - 1)) == 0) h = ((uint32_t)col[u] * 0x9E3779B1u) >> (32 - LOGT);
+						else h = (uint32_t)(((uint64_t)((uint32_t)col[u] * 0x9E3779B1u) * (uint64_t)T) >> 32);   // multiply-shift into [0, T)
 						for (;;) {
 							int32_t old = atomicCAS(&h_key[h], -1, col[u]);
 							if (old == -1) { isnew = true; break; }
 							if (old == col[u]) break;
-							h = (h + 1) & (T - 1);
+							if constexpr ((T & (T - 1)) == 0) h = (h + 1) & (T - 1);
+							else h = h + 1 == (uint32_t)T ? 0u : h + 1;
 						}
 						if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
 					}
@@ -763,11 +766,13 @@ __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint3
 	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
 }
 
-// Cell classes: 0..2 hash (T = 1024 / 4096 / 8192), 3 dense
-constexpr int NCLS = 4;
+// Cell classes: 0..3 hash (T = 1024 / 3072 / 4096 / 8192 slots; T/2 products), 4 dense
+constexpr int NCLS = 5;
+constexpr int CLS_DENSE = NCLS - 1;
 constexpr uint32_t CELL_CAP = 4096;      // largest hash cell (T = 8192)
-constexpr uint32_t CELL_CAP_DEFAULT = 2048;
-__device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 2048 ? 1 : 2); }
+constexpr uint32_t CELL_CAP_DEFAULT = 2048;      // greedy grouping target of the hash cells (measured best on R-MAT scale-20)
+constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // a single window above this becomes a dense cell
+__device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 1536 ? 1 : (prods <= 2048 ? 2 : 3)); }
 
 struct CellBases { uint32_t *base[NCLS]; };      // per heavy row: first cell index in each class list
 struct CellLists { Cell *list[NCLS]; };
@@ -776,7 +781,7 @@ struct CellLists { Cell *list[NCLS]; };
 // the cells per class (and the row's segment count); WRITE = true emits them.
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
-	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap,
+	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap, uint32_t dense_min,
 	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod)
 {
 	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -785,8 +790,8 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	Cell proto;
 	proto.beg = rbeg[r]; proto.end = rbeg[r + 1]; proto.rowid = rid[r]; proto.pad[0] = proto.pad[1] = 0;
 	const uint32_t *wp = winprod + (uint64_t)h * nwin;
-	uint32_t n[NCLS] = {0, 0, 0, 0};
-	unsigned long long np[NCLS] = {0, 0, 0, 0};
+	uint32_t n[NCLS] = {};
+	unsigned long long np[NCLS] = {};
 	uint32_t ordinal = 0;
 	uint32_t cur = 0, start = 0, last = 0;
 	auto flush = [&]() {
@@ -800,13 +805,18 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	};
 	for (uint32_t w = 0; w < nwin; ++w) {
 		uint32_t c = wp[w];
-		if (c > cell_cap) {
+		if (c > dense_min) {
 			flush();
 			if (WRITE) {
 				Cell d = proto; d.seg = segbase ? segbase[r] + ordinal : 0; d.prods = c; d.wa = (uint16_t)w; d.wb = (uint16_t)(w + 1);
-				lists.list[3][base.base[3][h] + n[3]] = d;
+				lists.list[CLS_DENSE][base.base[CLS_DENSE][h] + n[CLS_DENSE]] = d;
 			}
-			++n[3]; np[3] += c; ++ordinal;
+			++n[CLS_DENSE]; np[CLS_DENSE] += c; ++ordinal;
+		} else if (c > cell_cap) {
+			// too large for a group, too small for a dense window: a hash cell of its own
+			flush();
+			cur = c; start = last = w;
+			flush();
 		} else if (c > 0) {
 			if (cur + c > cell_cap) flush();
 			if (!cur) start = w;
@@ -1088,46 +1098,36 @@ struct Heavy {
 	uint32_t *bwin = nullptr;
 	uint32_t nwin = 0, nwin1 = 0;
 	uint32_t *winprod = nullptr;
-	uint32_t ncell[NCLS] = {0, 0, 0, 0};
-	Cell *cells[NCLS] = {nullptr, nullptr, nullptr, nullptr};
+	uint32_t ncell[NCLS] = {};
+	Cell *cells[NCLS] = {};
 	CellBases cnt{}, base{};
-	uint32_t *xb[NCLS] = {nullptr, nullptr, nullptr, nullptr};   // XCD part boundaries per class
+	uint32_t *xb[NCLS] = {};         // XCD part boundaries per class
 	int W = 8192;
-	uint32_t cell_cap = CELL_CAP_DEFAULT;
-	unsigned long long clsprod[NCLS] = {0, 0, 0, 0};
+	uint32_t cell_cap = CELL_CAP_DEFAULT, dense_min = DENSE_MIN_DEFAULT;
+	unsigned long long clsprod[NCLS] = {};
 };
 
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], hv.xb[0], m, hv.bwin, hv.nwin1, ep, sk);
-	static const int hnt = getenv("SPSAMD_HASH_NT") ? atoi(getenv("SPSAMD_HASH_NT")) : 512;
-	if (hnt == 1024) {
-		launch_hash<4096, 1024, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
-		launch_hash<8192, 1024, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
-		return;
-	}
-	if (hnt == 512) {
-		launch_hash<4096, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
-		launch_hash<8192, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
-		return;
-	}
-	launch_hash<4096, 256, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
-	launch_hash<8192, 256, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<3072, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<4096, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
+	launch_hash<8192, 512, MODE, true>(c, hv.cells[3], hv.ncell[3], hv.xb[3], m, hv.bwin, hv.nwin1, ep, sk);
 }
 
 template <int MODE>
 static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
-	if (!hv.ncell[3]) return;
+	if (!hv.ncell[CLS_DENSE]) return;
 	if (hv.W == 8192) {
-		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu * 2u);
+		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.xb[3], m, hv.bwin, hv.nwin1, ep, sk);
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, hv.bwin, hv.nwin1, ep, sk);
 	} else {
-		unsigned grid = std::min<unsigned>(hv.ncell[3], (unsigned)c->num_cu);
+		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[3], hv.ncell[3], hv.xb[3], m, hv.bwin, hv.nwin1, ep, sk);
+		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, hv.bwin, hv.nwin1, ep, sk);
 	}
 	SPS_LAUNCH_CHECK();
 }
@@ -1164,9 +1164,11 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		hv.base.base[k] = c->arena.get<uint32_t>((size_t)hv.n + 1);
 	}
 	if (const char *e = getenv("SPSAMD_CELL_CAP")) { int v = atoi(e); if (v >= 64 && v <= (int)CELL_CAP) hv.cell_cap = (uint32_t)v; }
+	if (const char *e = getenv("SPSAMD_DENSE_MIN")) { int v = atoi(e); if (v >= 64 && v <= (int)CELL_CAP) hv.dense_min = (uint32_t)v; }
+	if (hv.dense_min < hv.cell_cap) hv.dense_min = hv.cell_cap;
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod);
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
@@ -1179,16 +1181,16 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hipStream_t st = c->stream;
 	CellLists lists;
 	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.cnt, nullptr, hv.base, lists, segbase, nullptr);
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) {
 		uint32_t nd = hv.ncell[k];
 		if (nd < 2) continue;
 		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
 		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
-		k_cell_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == 3, k0);
+		k_cell_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == CLS_DENSE, k0);
 		SPS_LAUNCH_CHECK();
-		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == 3 ? 44 : 12);
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == CLS_DENSE ? 44 : 12);
 		Cell *sorted = c->arena.get<Cell>(nd);
 		k_gather_cells<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], where ? p1 : p0, nd, sorted);
 		SPS_LAUNCH_CHECK();
@@ -1203,7 +1205,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 		if (nd < 4096) continue;
 		uint32_t *cost = c->arena.get<uint32_t>(nd);
 		int64_t *pref = c->arena.get<int64_t>((size_t)nd + 1);
-		k_cell_cost<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == 3 ? 6000u : 2000u, cost);
+		k_cell_cost<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == CLS_DENSE ? 6000u : 2000u, cost);
 		SPS_LAUNCH_CHECK();
 		scan_exclusive_u32_i64(c, cost, pref, nd);
 		hv.xb[k] = c->arena.get<uint32_t>(9);
@@ -1310,9 +1312,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		k_row_cells<<<dim3(grid_for(nb)), dim3(256), 0, st>>>(bins.rows + bins.off[5 + k], nb, rl.beg, rl.id, rprod, segbase, mc.cells[k]);
 		SPS_LAUNCH_CHECK();
 	}
-	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2];
-	res->cells_dense = hv.ncell[3];
-	res->products_dense = hv.clsprod[3];
+	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3];
+	res->cells_dense = hv.ncell[CLS_DENSE];
+	res->products_dense = hv.clsprod[CLS_DENSE];
 	SPS_HIP(hipEventRecord(c->ev[2], st));
 
 	// ---- numeric
