@@ -11,13 +11,18 @@
 //              per lane, ranked by (col, k) through LDS, summed in ascending k
 //              (bit-identical to the reference's `sum += a*b` order,
 //              multiply_sparse.hpp:219-236) and compacted with ballot/popcount.
-//   mid        64 < P_r <= 4096: one workgroup per row, LDS hash accumulator
-//              keyed by column (ds_cmpswap + ds_add_f64), then an in-LDS
-//              bitonic sort of the surviving columns for ordered emission.
-//   heavy      P_r > 4096: persistent workgroups pull rows from a ticket; the
-//              column space is cut into windows of W columns whose dense f64
-//              accumulator lives in LDS; B's row panels are pre-indexed per
-//              window so each (row, window) reads exactly its B segments.
+//   cells      above the light bin the unit of work is a cell: one output row
+//              restricted to a range of column windows (W = 8192 or 16384
+//              columns).  A mid row (P_r <= 4096) is one cell.  A heavy row's
+//              windows are grouped greedily into hash cells of <= 2048 products;
+//              a single window with more becomes a dense cell.  B's row panels
+//              are pre-indexed per window (bwin) so a cell reads exactly its B
+//              segments; the cell lists are sorted window-major for L2 locality.
+//   hash       persistent workgroups; LDS hash accumulator keyed by column
+//              (ds_cmpswap + ds_add_f64) with a list of occupied slots, then an
+//              in-LDS bitonic sort of the surviving columns for ordered emission.
+//   dense      persistent workgroups; dense f64 accumulator of W columns in LDS
+//              (ds_add_f64), scanned out in ascending column order.
 //
 // Output semantics follow multiply_sparse.hpp:238-243: exact-zero sums are
 // dropped, value = sum * C * a_scale * b_scale, tuples in ascending (i, j).
@@ -848,8 +853,8 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 
 // ====================================================================== dense cells (f64 window accumulator in LDS)
 
-// Persistent workgroups pull dense cells (one window of one row, > 4096
-// products) from a ticket, largest first.
+// Persistent workgroups walk the dense cells (one window of one row holding
+// more products than a hash cell takes) with a grid stride.
 template <int W, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
