@@ -60,6 +60,21 @@ struct SinkParams {
 	long long *row_nnz; double *row_sum;   // optional row statistics (DIGEST)
 };
 
+// One B tuple as the numeric kernels read it: column and value side by side (12 bytes), so
+// a short B segment sits in one or two cache lines instead of two partial lines of separate
+// col[] / val[] arrays.  Same bytes per product as the SoA form (12 B).
+struct __attribute__((packed, aligned(4))) BTup { int32_t col; uint32_t vlo, vhi; };
+__device__ __forceinline__ double btup_val(const BTup &t) { return __hiloint2double((int)t.vhi, (int)t.vlo); }
+
+__global__ void k_pack_b(const int32_t *bcol, const double *bval, uint32_t n, BTup *out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	double v = bval[i];
+	BTup t; t.col = bcol[i]; t.vlo = (uint32_t)__double2loint(v); t.vhi = (uint32_t)__double2hiint(v);
+	out[i] = t;
+}
+
 struct RowMeta {
 	const uint32_t *beg;            // per non-empty A row: first tuple (+ sentinel)
 	const int32_t *id;              // per non-empty A row: row index
@@ -68,6 +83,7 @@ struct RowMeta {
 	const uint32_t *bptr;           // B dense row pointer
 	const int32_t *bcol;
 	const double *bval;
+	const BTup *btup;               // B tuples, (col, val) interleaved
 	const uint32_t *elo;            // A tuples: first B tuple of the selected row (bptr[k])
 	const uint32_t *elen;           // A tuples: length of the selected B row
 };
@@ -275,8 +291,9 @@ __global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t
 	double prod = 0;
 	if (act) {
 		uint32_t ap = s_apos[w][lane], bp = s_bpos[w][lane];
-		prod = m.aval[ap] * m.bval[bp];
-		key = ((uint64_t)(uint32_t)m.bcol[bp] << 32) | (uint64_t)ap;
+		const BTup t = m.btup[bp];
+		prod = m.aval[ap] * btup_val(t);
+		key = ((uint64_t)(uint32_t)t.col << 32) | (uint64_t)ap;
 	}
 	s_key[w][lane] = key;
 	wave_lds_sync();
@@ -522,20 +539,25 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 	// Software pipeline over the cells of this workgroup: the record of cell i+2, the A tuples of
 	// cell i+1 and then its B segment bounds are loaded while cell i is processed (the barriers
 	// inside are LDS-only, so these loads stay in flight).
+	// The prefetches are branch-free (indices clamped to valid cells / tuples, results masked
+	// afterwards): a load inside a conditional is waited for at the join, which would serialise it.
 	const CellWalk walk = cell_walk(xb, ncell);
 	const uint32_t stride = walk.stride, cend = walk.end;
-	Cell rec1{}, rec2{};
-	if (walk.first < cend) rec1 = cells[walk.first];
-	if (walk.first + stride < cend) rec2 = cells[walk.first + stride];
-	uint32_t nlo = 0, nlen = 0; double na = 0;
+	const bool any_cell = walk.first < cend;
+	const uint32_t clast = any_cell ? cend - 1 : 0;
+	Cell rec1 = cells[min(walk.first, clast)];
+	Cell rec2 = cells[min(walk.first + stride, clast)];
+	uint32_t nlo, nlen; double na;
 	{
-		uint32_t e = rec1.beg + tid;
-		if (walk.first < cend && e < rec1.end) {
-			int32_t k = m.acol[e];
-			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)k * nwin1; nlo = bw[rec1.wa]; nlen = bw[rec1.wb] - nlo; }
-			else { nlo = m.bptr[k]; nlen = m.bptr[k + 1] - nlo; }
-			na = m.aval[e];
-		}
+		const uint32_t e = rec1.beg + tid;
+		const bool act = e < rec1.end;
+		const uint32_t ec = act ? e : rec1.beg;
+		const int32_t k = m.acol[ec];
+		uint32_t lo, hi;
+		if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)k * nwin1; lo = bw[rec1.wa]; hi = bw[rec1.wb]; }
+		else { lo = m.bptr[k]; hi = m.bptr[k + 1]; }
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u;
 	}
 	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
 		const Cell cell = rec1;
@@ -544,13 +566,12 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
 		// stage A / B of the pipeline
 		rec1 = rec2;
-		if (ci + 2 * stride < cend) rec2 = cells[ci + 2 * stride];
-		int32_t nk = 0; bool nact = false;
-		if (ci + stride < cend) {
-			uint32_t e = rec1.beg + tid;
-			nact = e < rec1.end;
-			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
-		}
+		rec2 = cells[min(ci + 2 * stride, clast)];
+		const uint32_t ne = rec1.beg + tid;
+		const bool nact = (ci + stride < cend) && ne < rec1.end;
+		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
 		if (cell.prods > (uint32_t)(T / 2)) continue;               // never: the class bounds the cell (guards the LDS tables)
 		lds_barrier();                                              // previous cell fully emitted, its s_nocc read
 		if (tid == 0) s_nocc = 0;
@@ -583,8 +604,9 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 					p = ok[u] ? p : total - 1;
 					uint32_t q = expand_lookup(X, p, 0);
 					uint32_t bp = X.cstart[q] + (p - X.cpref[q]);
-					col[u] = m.bcol[bp];
-					pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * m.bval[bp] : 0.0;
+					const BTup t = m.btup[bp];
+					col[u] = t.col;
+					pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * btup_val(t) : 0.0;
 				}
 #pragma unroll
 				for (int u = 0; u < U; ++u) {
@@ -615,11 +637,12 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			lds_barrier();
 		}
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
-		nlo = 0; nlen = 0;
-		if (nact) {
-			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1; nlo = bw[rec1.wa]; nlen = bw[rec1.wb] - nlo; }
-			else { nlo = m.bptr[nk]; nlen = m.bptr[nk + 1] - nlo; }
-		} else na = 0;
+		{
+			uint32_t lo, hi;
+			if (WINDOWED) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1; lo = bw[rec1.wa]; hi = bw[rec1.wb]; }
+			else { lo = m.bptr[nk]; hi = m.bptr[nk + 1]; }
+			nlo = lo; nlen = nact ? hi - lo : 0u;
+		}
 		lds_barrier();
 		uint32_t nocc = s_nocc;
 		if (ep.dbg & 2) nocc = 0;
@@ -880,17 +903,19 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 	// Same three-stage software pipeline as k_hash.
 	const CellWalk walk = cell_walk(xb, ncell);
 	const uint32_t stride = walk.stride, cend = walk.end;
-	Cell rec1{}, rec2{};
-	if (walk.first < cend) rec1 = cells[walk.first];
-	if (walk.first + stride < cend) rec2 = cells[walk.first + stride];
-	uint32_t nlo = 0, nlen = 0; double na = 0;
+	const bool any_cell = walk.first < cend;
+	const uint32_t clast = any_cell ? cend - 1 : 0;
+	Cell rec1 = cells[min(walk.first, clast)];
+	Cell rec2 = cells[min(walk.first + stride, clast)];
+	uint32_t nlo, nlen; double na;
 	{
-		uint32_t e = rec1.beg + tid;
-		if (walk.first < cend && e < rec1.end) {
-			const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1 + rec1.wa;
-			nlo = bw[0]; nlen = bw[1] - nlo;
-			na = m.aval[e];
-		}
+		const uint32_t e = rec1.beg + tid;
+		const bool act = e < rec1.end;
+		const uint32_t ec = act ? e : rec1.beg;
+		const uint32_t *bw = bwin + (uint64_t)m.acol[ec] * nwin1 + rec1.wa;
+		const uint32_t lo = bw[0], hi = bw[1];
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u;
 	}
 	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
 		const Cell cell = rec1;
@@ -901,13 +926,12 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		const uint32_t wbase = w << WSHIFT;
 		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
 		rec1 = rec2;
-		if (ci + 2 * stride < cend) rec2 = cells[ci + 2 * stride];
-		int32_t nk = 0; bool nact = false;
-		if (ci + stride < cend) {
-			uint32_t e = rec1.beg + tid;
-			nact = e < rec1.end;
-			if (nact) { nk = m.acol[e]; na = m.aval[e]; }
-		}
+		rec2 = cells[min(ci + 2 * stride, clast)];
+		const uint32_t ne = rec1.beg + tid;
+		const bool nact = (ci + stride < cend) && ne < rec1.end;
+		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
 		lds_barrier();                                              // previous cell's scan-out complete
 
 		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
@@ -947,7 +971,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 					}
 					uint32_t col[U]; double bv[U];
 #pragma unroll
-					for (int u = 0; u < U; ++u) { col[u] = (uint32_t)m.bcol[bp[u]]; if (MODE != MODE_COUNT) bv[u] = m.bval[bp[u]]; }
+					for (int u = 0; u < U; ++u) { const BTup t = m.btup[bp[u]]; col[u] = (uint32_t)t.col; bv[u] = btup_val(t); }
 #pragma unroll
 					for (int u = 0; u < U; ++u) {
 						uint32_t slot = col[u] - wbase;
@@ -959,8 +983,11 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			}
 		}
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
-		nlo = 0; nlen = 0;
-		if (nact) { const uint32_t *bw = bwin + (uint64_t)nk * nwin1 + rec1.wa; nlo = bw[0]; nlen = bw[1] - nlo; } else na = 0;
+		{
+			const uint32_t *bw = bwin + (uint64_t)nk * nwin1 + rec1.wa;
+			const uint32_t lo = bw[0], hi = bw[1];
+			nlo = lo; nlen = nact ? hi - lo : 0u;
+		}
 		if (ep.dbg & 16) continue;
 		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
 		double v[GPW];
@@ -1287,7 +1314,10 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->tuples_mid = hbc.tuples[5] + hbc.tuples[6] + hbc.tuples[7];
 	res->tuples_heavy = hbc.tuples[8];
 
-	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val, elo, elen};
+	BTup *btup = c->arena.get<BTup>(B.nnz);
+	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
+	SPS_LAUNCH_CHECK();
+	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val, btup, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
 		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0};
 
