@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			expand_load(X, lo, len, a, &total, &nzc, flip);
 			if (total == 0) continue;
 			if (!(ep.dbg & 4)) expand_batch(X, 0, total, nzc);
-			constexpr int U = 2;
+			constexpr int U = 4;
 			if (ep.dbg & 1) total = 0;
 			for (uint32_t pbase = 0; pbase < total; pbase += NT * U) {
 				// U products per thread and step: issue all B loads before the first insertion
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 				// U products per thread and step: all B loads of a step are issued before the first
 				// is used (the loop is bound by load latency, not by bandwidth or issue rate).
 				// A thread past the end re-reads the last product with weight 0.
-				constexpr int U = 4;
+				constexpr int U = 2;
 				for (uint32_t p0 = pb + tid; p0 < pe; p0 += NT * U) {
 					uint32_t bp[U]; double av[U];
 #pragma unroll
