@@ -402,7 +402,7 @@ struct Expand {
 // barrier inside; the arrays become visible at expand_batch's first barrier.
 template <int NT, int PB>
 __device__ __forceinline__ void expand_load(Expand<NT, PB> &L, uint32_t lo, uint32_t len, double a, uint32_t *total, uint32_t *nzc,
-	uint32_t &flip)
+	uint32_t &flip, uint32_t *ex_out)
 {
 	constexpr int NW = NT / 64;
 	const uint32_t inc = wave_inclusive_scan_u32(len);
@@ -419,6 +419,7 @@ __device__ __forceinline__ void expand_load(Expand<NT, PB> &L, uint32_t lo, uint
 		totL += l; totN += n;
 	}
 	flip ^= 1u;
+	*ex_out = baseL + inc - len;                 // exclusive product prefix of this thread's segment
 	if (len) {
 		uint32_t rank = baseN + wrank;
 		L.cpref[rank] = baseL + inc - len;
@@ -511,16 +512,152 @@ __global__ void k_row_cells(const uint32_t *binrows, uint32_t n, const uint32_t 
 	cells[i] = c;
 }
 
-// Persistent workgroups walk the cell list with a grid stride (the list is in
-// window-major order, so concurrently processed cells read the same column
-// windows of B).  T hash slots (T/2 = the product cap of the class); the table
-// is cleaned as it is emitted (list of occupied slots), so a cell costs work
-// proportional to its products, not to T.
+// ---- LDS hash accumulator shared by k_hash and k_hash_tiles -----------------------------
+// T slots (power of two or 3072), at most T/2 products per cell.  The table is cleaned as it
+// is emitted (list of occupied slots), so a cell costs work proportional to its products.
+
+template <int T>
+__device__ __forceinline__ uint32_t hash_slot(int32_t col)
+{
+	constexpr int LOGT = T == 1024 ? 10 : (T == 2048 ? 11 : (T == 4096 ? 12 : 13));   // power-of-two T only
+	if constexpr ((T & (T - 1)) == 0) return ((uint32_t)col * 0x9E3779B1u) >> (32 - LOGT);
+	else return (uint32_t)(((uint64_t)((uint32_t)col * 0x9E3779B1u) * (uint64_t)T) >> 32);   // multiply-shift into [0, T)
+}
+
+// Products [p0, p1) of the prepared batch starting at pb -> table.  U products per thread and
+// step: all B loads of a step are issued before the first insertion.
+template <int T, int NT, int PB, int MODE>
+__device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t p0, uint32_t p1, uint32_t pb, const RowMeta &m,
+	int32_t *h_key, double *h_val, uint16_t *occ, uint32_t *s_nocc)
+{
+	constexpr int U = 4;
+	const unsigned tid = threadIdx.x;
+	for (uint32_t pbase = p0; pbase < p1; pbase += NT * U) {
+		int32_t col[U]; double pv[U]; bool ok[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			uint32_t p = pbase + u * NT + tid;
+			ok[u] = p < p1;
+			p = ok[u] ? p : p1 - 1;
+			uint32_t q = expand_lookup(X, p, pb);
+			uint32_t bp = X.cstart[q] + (p - X.cpref[q]);
+			const BTup t = m.btup[bp];
+			col[u] = t.col;
+			pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * btup_val(t) : 0.0;
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			bool isnew = false;
+			uint32_t h = 0;
+			if (ok[u]) {
+				h = hash_slot<T>(col[u]);
+				for (;;) {
+					int32_t old = atomicCAS(&h_key[h], -1, col[u]);
+					if (old == -1) { isnew = true; break; }
+					if (old == col[u]) break;
+					if constexpr ((T & (T - 1)) == 0) h = (h + 1) & (T - 1);
+					else h = h + 1 == (uint32_t)T ? 0u : h + 1;
+				}
+				if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
+			}
+			// append the newly occupied slots (one LDS atomic per wave)
+			uint64_t nm = __ballot(isnew);
+			if (nm) {
+				uint32_t base = 0;
+				if (lane_id() == 0) base = atomicAdd(s_nocc, (uint32_t)__popcll(nm));
+				base = (uint32_t)__shfl((int)base, 0, 64);
+				if (isnew) occ[base + __popcll(nm & lanemask_lt())] = (uint16_t)h;
+			}
+		}
+	}
+}
+
+struct DigestAcc { unsigned long long cnt, hash; double sum; };
+
+// Emit the occupied slots of the finished cell into the sink and clean them.
+template <int T, int NT, int MODE>
+__device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t seg, const EmitParams &ep, const SinkParams &sk,
+	int32_t *h_key, double *h_val, const uint16_t *occ, uint64_t *s_sort, uint32_t *scr32, DigestAcc &d)
+{
+	const unsigned tid = threadIdx.x;
+	const double a_scale = row_scale(ep, rowid);
+	if (MODE == MODE_COUNT) {
+		// structural count (an upper bound when sums cancel to exactly 0)
+		uint32_t c = 0;
+		for (uint32_t i = tid; i < nocc; i += NT) { uint32_t h = occ[i]; if (col_allowed(ep, h_key[h])) ++c; h_key[h] = -1; }
+		uint32_t total;
+		block_exclusive_scan<uint32_t, NT>(c, scr32, &total);
+		if (tid == 0) sk.segcount[seg] = total;
+	} else if (MODE == MODE_DIGEST) {
+		unsigned long long cnt = 0; double vs = 0;
+		for (uint32_t i = tid; i < nocc; i += NT) {
+			uint32_t h = occ[i];
+			int32_t col = h_key[h];
+			double v;
+			if (emit_value(ep, a_scale, col, h_val[h], &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+			h_key[h] = -1; h_val[h] = 0.0;
+		}
+		d.cnt += cnt; d.sum += vs;
+		if (sk.row_nnz) {
+			unsigned long long rc = wave_reduce_sum(cnt); double rs = wave_reduce_sum(vs);
+			if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+		}
+	} else {
+		// surviving (col, slot) pairs -> bitonic sort by column -> emit in order, cleaning the table
+		uint32_t run = 0;
+		for (uint32_t base = 0; base < nocc; base += NT) {
+			uint32_t i = base + tid;
+			bool ok = false;
+			uint32_t h = 0; int32_t col = 0;
+			if (i < nocc) {
+				h = occ[i]; col = h_key[h];
+				double v = 0;
+				ok = emit_value(ep, a_scale, col, h_val[h], &v);
+				h_key[h] = -1;
+				h_val[h] = ok ? v : 0.0;
+			}
+			uint32_t total;
+			uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, scr32, &total);
+			if (ok) s_sort[run + ex] = ((uint64_t)(uint32_t)col << 16) | (uint64_t)h;
+			run += total;
+		}
+		const uint32_t mcount = run;
+		uint32_t n2 = 1;
+		while (n2 < mcount) n2 <<= 1;
+		for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
+		__syncthreads();
+		for (uint32_t k = 2; k <= n2; k <<= 1) {
+			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for (uint32_t i = tid; i < n2; i += NT) {
+					uint32_t ixj = i ^ j;
+					if (ixj > i) {
+						uint64_t x = s_sort[i], y = s_sort[ixj];
+						bool up = (i & k) == 0;
+						if ((x > y) == up) { s_sort[i] = y; s_sort[ixj] = x; }
+					}
+				}
+				__syncthreads();
+			}
+		}
+		int64_t o = sk.segoff[seg];
+		for (uint32_t i = tid; i < mcount; i += NT) {
+			uint64_t kq = s_sort[i];
+			uint32_t h = (uint32_t)(kq & 0xFFFFu);
+			sk.out_i[o + i] = rowid;
+			sk.out_j[o + i] = (int32_t)(kq >> 16);
+			sk.out_v[o + i] = h_val[h];
+			h_val[h] = 0.0;
+		}
+		if (tid == 0) sk.segactual[seg] = mcount;
+	}
+}
+
+// Persistent workgroups walk the cell list with a grid stride (the list is in window-major
+// order, so concurrently processed cells read the same column windows of B).
 template <int T, int NT, int MODE, bool WINDOWED>
 __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
-	constexpr int LOGT = T == 1024 ? 10 : (T == 2048 ? 11 : (T == 4096 ? 12 : 13));   // power-of-two T only
 	__shared__ int32_t h_key[T];
 	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
 	__shared__ uint16_t occ[T / 2];
@@ -533,7 +670,7 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 
 	const unsigned tid = threadIdx.x;
 	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
-	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
+	DigestAcc dacc{0, 0, 0.0};                                      // DIGEST, whole launch
 	uint32_t flip = 0;
 
 	// Software pipeline over the cells of this workgroup: the record of cell i+2, the A tuples of
@@ -588,52 +725,12 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 					a = m.aval[e];
 				}
 			}
-			uint32_t total, nzc;
-			expand_load(X, lo, len, a, &total, &nzc, flip);
+			uint32_t total, nzc, ex;
+			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 			if (total == 0) continue;
 			if (!(ep.dbg & 4)) expand_batch(X, 0, total, nzc);
-			constexpr int U = 4;
 			if (ep.dbg & 1) total = 0;
-			for (uint32_t pbase = 0; pbase < total; pbase += NT * U) {
-				// U products per thread and step: issue all B loads before the first insertion
-				int32_t col[U]; double pv[U]; bool ok[U];
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					uint32_t p = pbase + u * NT + tid;
-					ok[u] = p < total;
-					p = ok[u] ? p : total - 1;
-					uint32_t q = expand_lookup(X, p, 0);
-					uint32_t bp = X.cstart[q] + (p - X.cpref[q]);
-					const BTup t = m.btup[bp];
-					col[u] = t.col;
-					pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * btup_val(t) : 0.0;
-				}
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					bool isnew = false;
-					uint32_t h = 0;
-					if (ok[u]) {
-						if constexpr ((T & (T - 1)) == 0) h = ((uint32_t)col[u] * 0x9E3779B1u) >> (32 - LOGT);
-						else h = (uint32_t)(((uint64_t)((uint32_t)col[u] * 0x9E3779B1u) * (uint64_t)T) >> 32);   // multiply-shift into [0, T)
-						for (;;) {
-							int32_t old = atomicCAS(&h_key[h], -1, col[u]);
-							if (old == -1) { isnew = true; break; }
-							if (old == col[u]) break;
-							if constexpr ((T & (T - 1)) == 0) h = (h + 1) & (T - 1);
-							else h = h + 1 == (uint32_t)T ? 0u : h + 1;
-						}
-						if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
-					}
-					// append the newly occupied slots (one LDS atomic per wave)
-					uint64_t nm = __ballot(isnew);
-					if (nm) {
-						uint32_t base = 0;
-						if (lane_id() == 0) base = atomicAdd(&s_nocc, (uint32_t)__popcll(nm));
-						base = (uint32_t)__shfl((int)base, 0, 64);
-						if (isnew) occ[base + __popcll(nm & lanemask_lt())] = (uint16_t)h;
-					}
-				}
-			}
+			hash_products<T, NT, T / 2, MODE>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc);
 			lds_barrier();
 		}
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
@@ -646,78 +743,116 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		lds_barrier();
 		uint32_t nocc = s_nocc;
 		if (ep.dbg & 2) nocc = 0;
-		const double a_scale = row_scale(ep, rowid);
-		if (MODE == MODE_COUNT) {
-			// structural count (an upper bound when sums cancel to exactly 0)
-			uint32_t c = 0;
-			for (uint32_t i = tid; i < nocc; i += NT) { uint32_t h = occ[i]; if (col_allowed(ep, h_key[h])) ++c; h_key[h] = -1; }
-			uint32_t total;
-			block_exclusive_scan<uint32_t, NT>(c, scr32, &total);
-			if (tid == 0) sk.segcount[seg] = total;
-		} else if (MODE == MODE_DIGEST) {
-			unsigned long long cnt = 0; double vs = 0;
-			for (uint32_t i = tid; i < nocc; i += NT) {
-				uint32_t h = occ[i];
-				int32_t col = h_key[h];
-				double v;
-				if (emit_value(ep, a_scale, col, h_val[h], &v)) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
-				h_key[h] = -1; h_val[h] = 0.0;
-			}
-			d_cnt += cnt; d_sum += vs;
-			if (sk.row_nnz) {
-				unsigned long long rc = wave_reduce_sum(cnt); double rs = wave_reduce_sum(vs);
-				if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
-			}
-		} else {
-			// surviving (col, slot) pairs -> bitonic sort by column -> emit in order, cleaning the table
-			uint32_t run = 0;
-			for (uint32_t base = 0; base < nocc; base += NT) {
-				uint32_t i = base + tid;
-				bool ok = false;
-				uint32_t h = 0; int32_t col = 0;
-				if (i < nocc) {
-					h = occ[i]; col = h_key[h];
-					double v = 0;
-					ok = emit_value(ep, a_scale, col, h_val[h], &v);
-					h_key[h] = -1;
-					h_val[h] = ok ? v : 0.0;
-				}
-				uint32_t total;
-				uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, scr32, &total);
-				if (ok) s_sort[run + ex] = ((uint64_t)(uint32_t)col << 16) | (uint64_t)h;
-				run += total;
-			}
-			const uint32_t mcount = run;
-			uint32_t n2 = 1;
-			while (n2 < mcount) n2 <<= 1;
-			for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
-			__syncthreads();
-			for (uint32_t k = 2; k <= n2; k <<= 1) {
-				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-					for (uint32_t i = tid; i < n2; i += NT) {
-						uint32_t ixj = i ^ j;
-						if (ixj > i) {
-							uint64_t x = s_sort[i], y = s_sort[ixj];
-							bool up = (i & k) == 0;
-							if ((x > y) == up) { s_sort[i] = y; s_sort[ixj] = x; }
-						}
-					}
-					__syncthreads();
-				}
-			}
-			int64_t o = sk.segoff[seg];
-			for (uint32_t i = tid; i < mcount; i += NT) {
-				uint64_t kq = s_sort[i];
-				uint32_t h = (uint32_t)(kq & 0xFFFFu);
-				sk.out_i[o + i] = rowid;
-				sk.out_j[o + i] = (int32_t)(kq >> 16);
-				sk.out_v[o + i] = h_val[h];
-				h_val[h] = 0.0;
-			}
-			if (tid == 0) sk.segactual[seg] = mcount;
+		hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc);
+	}
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
+}
+
+// ---- tiles: several hash cells of ONE heavy row share the segment expansion ---------------
+// A heavy row with L <= 256 A tuples has its hash cells (<= 2048 products each) grouped into
+// tiles of up to NT / Lp cells (Lp = L rounded up to a power of two) and <= TILE_PB products.
+// Thread t of the workgroup owns (cell t / Lp, tuple t % Lp): ONE expansion serves every cell of
+// the tile; the cells are then accumulated one after the other in the same LDS table.
+constexpr int TILE_NT = 512;
+constexpr int TILE_T = 4096;
+constexpr int TILE_PB = 16384;
+constexpr uint32_t TILE_LMAX = 256;
+constexpr uint32_t TILE_MAXCELLS = 16;
+
+struct TCell { uint16_t wa, wb; uint32_t seg; uint32_t prods; };
+struct Tile { uint32_t beg, end; int32_t rowid; uint32_t first, ncells, wa0, prods, pad; };
+
+template <int MODE>
+__global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
+	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
+{
+	constexpr int NT = TILE_NT, T = TILE_T;
+	__shared__ int32_t h_key[T];
+	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
+	__shared__ uint16_t occ[T / 2];
+	__shared__ uint64_t s_sort[MODE == MODE_STORE ? T / 2 : 1];
+	__shared__ Expand<NT, TILE_PB> X;
+	__shared__ uint32_t scr32[NT / 64 + 1];
+	__shared__ uint32_t s_nocc;
+	__shared__ uint32_t cellP[TILE_MAXCELLS + 1];
+	__shared__ unsigned long long s_u64[2 * (NT / 64)];
+	__shared__ double s_f64[NT / 64];
+
+	const unsigned tid = threadIdx.x;
+	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
+	DigestAcc dacc{0, 0, 0.0};
+	uint32_t flip = 0;
+
+	const uint32_t stride = gridDim.x;
+	const uint32_t tlast = ntile - 1;
+	// three-stage branch-free prefetch: tile record -> (A tuple, cell window range) -> B segment bounds
+	Tile rec1 = tiles[min(blockIdx.x, tlast)];
+	Tile rec2 = tiles[min(blockIdx.x + stride, tlast)];
+	uint32_t nlo, nlen, nseg_; double na;
+	{
+		const uint32_t L = rec1.end - rec1.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		const uint32_t c = tid >> lsh, ei = tid & ((1u << lsh) - 1u);
+		const bool act = c < rec1.ncells && ei < L;
+		const uint32_t ec = rec1.beg + (ei < L ? ei : 0u);
+		const TCell tc = tcells[rec1.first + (c < rec1.ncells ? c : 0u)];
+		const uint32_t *bw = bwin + (uint64_t)m.acol[ec] * nwin1;
+		const uint32_t lo = bw[tc.wa], hi = bw[tc.wb];
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u; nseg_ = tc.seg;
+	}
+	for (uint32_t ti = blockIdx.x; ti < ntile; ti += stride) {
+		const Tile tile = rec1;
+		const uint32_t lo = nlo, len = nlen, myseg = nseg_; const double a = na;
+		const uint32_t L = tile.end - tile.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		const uint32_t myc = tid >> lsh, myei = tid & ((1u << lsh) - 1u);
+		// stage A / B for the next tile
+		rec1 = rec2;
+		rec2 = tiles[min(ti + 2 * stride, tlast)];
+		const bool has_next = ti + stride < ntile;
+		const uint32_t nL = rec1.end - rec1.beg;
+		uint32_t nsh = 0;
+		while ((1u << nsh) < nL) ++nsh;
+		const uint32_t nc = tid >> nsh, nei = tid & ((1u << nsh) - 1u);
+		const bool nact = has_next && nc < rec1.ncells && nei < nL;
+		const uint32_t nec = rec1.beg + (nei < nL ? nei : 0u);
+		const TCell ntc = tcells[rec1.first + (nc < rec1.ncells ? nc : 0u)];
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
+
+		lds_barrier();                                              // previous tile fully emitted
+		uint32_t total, nzc, ex;
+		expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
+		if (myei == 0 && myc < tile.ncells) cellP[myc] = ex;       // first product of each cell
+		if (tid == 0) { cellP[tile.ncells] = total; s_nocc = 0; }
+		// segment ids of the cells of this tile: thread (c, 0) holds cell c's
+		const uint32_t seg_of_mine = myseg;
+		if (total) expand_batch(X, 0, total, nzc);
+		else lds_barrier();
+		// stage C: B segment bounds of the next tile
+		{
+			const uint32_t *bw = bwin + (uint64_t)nk * nwin1;
+			const uint32_t nlo_ = bw[ntc.wa], nhi_ = bw[ntc.wb];
+			nlo = nlo_; nlen = nact ? nhi_ - nlo_ : 0u; nseg_ = ntc.seg;
+		}
+		for (uint32_t c = 0; c < tile.ncells; ++c) {
+			const uint32_t p0 = cellP[c], p1 = cellP[c + 1];
+			hash_products<T, NT, TILE_PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
+			lds_barrier();
+			const uint32_t nocc = s_nocc;
+			// the cell's output segment id lives in thread (c, 0): broadcast through LDS
+			if (myc == c && myei == 0) scr32[NT / 64] = seg_of_mine;
+			lds_barrier();
+			const uint32_t seg = scr32[NT / 64];
+			if (tid == 0) s_nocc = 0;
+			hash_emit<T, NT, MODE>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc);
+			lds_barrier();
 		}
 	}
-	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
 }
 
 // ====================================================================== heavy rows: window index, cells
@@ -807,10 +942,13 @@ struct CellLists { Cell *list[NCLS]; };
 
 // Greedy grouping of a heavy row's windows into cells.  WRITE = false counts
 // the cells per class (and the row's segment count); WRITE = true emits them.
+struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; };
+
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
 	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap, uint32_t dense_min,
-	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod)
+	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod,
+	TileBases tb)
 {
 	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
 	if (h >= nheavy) return;
@@ -822,8 +960,37 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	unsigned long long np[NCLS] = {};
 	uint32_t ordinal = 0;
 	uint32_t cur = 0, start = 0, last = 0;
+	// rows with few A tuples: their hash cells are grouped into tiles that share one expansion
+	const uint32_t L = proto.end - proto.beg;
+	const bool tileable = tb.enabled && L <= TILE_LMAX;
+	uint32_t lsh = 0;
+	while ((1u << lsh) < L) ++lsh;
+	const uint32_t G = min((uint32_t)TILE_NT >> lsh, TILE_MAXCELLS);
+	uint32_t ntc = 0, ntl = 0;                    // tile cells / tiles emitted so far for this row
+	uint32_t tcnt = 0, tprods = 0, tfirst = 0, twa0 = 0;   // the open tile
+	auto close_tile = [&]() {
+		if (!tcnt) return;
+		if (WRITE) {
+			Tile t; t.beg = proto.beg; t.end = proto.end; t.rowid = proto.rowid; t.first = tb.tcbase[h] + tfirst; t.ncells = tcnt;
+			t.wa0 = twa0; t.prods = tprods; t.pad = 0;
+			tb.tiles[tb.tlbase[h] + ntl] = t;
+		}
+		++ntl; tcnt = 0; tprods = 0;
+	};
 	auto flush = [&]() {
 		if (!cur) return;
+		if (tileable && cur <= (uint32_t)(TILE_T / 2)) {
+			if (tcnt == G || tprods + cur > (uint32_t)TILE_PB) close_tile();
+			if (!tcnt) { tfirst = ntc; twa0 = start; }
+			if (WRITE) {
+				TCell tc; tc.wa = (uint16_t)start; tc.wb = (uint16_t)(last + 1); tc.seg = segbase ? segbase[r] + ordinal : 0; tc.prods = cur;
+				tb.tcells[tb.tcbase[h] + ntc] = tc;
+			}
+			++ntc; ++tcnt; tprods += cur;
+			np[0] += cur;                           // counted with the hash products
+			++ordinal; cur = 0;
+			return;
+		}
 		int cls = hash_class(cur);
 		if (WRITE) {
 			Cell c = proto; c.seg = segbase ? segbase[r] + ordinal : 0; c.prods = cur; c.wa = (uint16_t)start; c.wb = (uint16_t)(last + 1);
@@ -852,11 +1019,25 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		}
 	}
 	flush();
+	close_tile();
 	if (!WRITE) {
 #pragma unroll
 		for (int k = 0; k < NCLS; ++k) { cnt.base[k][h] = n[k]; if (np[k]) atomicAdd(&clsprod[k], np[k]); }
 		nseg[r] = ordinal;
+		if (tb.enabled) { tb.ntc[h] = ntc; tb.ntl[h] = ntl; }
 	}
+}
+
+__global__ void k_tile_keys(const Tile *tiles, uint32_t n, uint64_t *keys)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) keys[i] = tiles[i].wa0;             // window-major, stable
+}
+
+__global__ void k_gather_tiles(const Tile *src, const uint32_t *perm, uint32_t n, Tile *dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[perm[i]];
 }
 
 __global__ void k_cell_keys(const Cell *cells, uint32_t n, int by_size, uint64_t *keys)
@@ -946,8 +1127,8 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 					a = m.aval[e];
 				}
 			}
-			uint32_t total, nzc;
-			expand_load(X, lo, len, a, &total, &nzc, flip);
+			uint32_t total, nzc, ex;
+			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 			if (total == 0) continue;                               // uniform
 			if (ep.dbg & 8) total = 0;
 			// products of the chunk in batches of W
@@ -1136,12 +1317,25 @@ struct Heavy {
 	uint32_t *xb[NCLS] = {};         // XCD part boundaries per class
 	int W = 8192;
 	uint32_t cell_cap = CELL_CAP_DEFAULT, dense_min = DENSE_MIN_DEFAULT;
+	TileBases tb{};
+	uint32_t ntile = 0, ntcell = 0;
 	unsigned long long clsprod[NCLS] = {};
 };
 
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
+	if (hv.ntile) {
+		static int per_cu = 0;
+		if (!per_cu) {
+			int nb = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash_tiles<MODE>, TILE_NT, 0) != hipSuccess || nb < 1) nb = 1;
+			per_cu = nb;
+		}
+		unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)(c->num_cu * per_cu));
+		k_hash_tiles<MODE><<<dim3(grid), dim3(TILE_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, ep, sk);
+		SPS_LAUNCH_CHECK();
+	}
 	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], hv.xb[0], m, hv.bwin, hv.nwin1, ep, sk);
 	launch_hash<3072, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
 	launch_hash<4096, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
@@ -1200,10 +1394,18 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	if (hv.dense_min < hv.cell_cap) hv.dense_min = hv.cell_cap;
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod);
+	hv.tb.enabled = !(getenv("SPSAMD_NO_TILES") && atoi(getenv("SPSAMD_NO_TILES")));
+	hv.tb.ntc = c->arena.get<uint32_t>(hv.n); hv.tb.ntl = c->arena.get<uint32_t>(hv.n);
+	hv.tb.tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); hv.tb.tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
+	fill_zero(c, hv.tb.ntc, hv.n * sizeof(uint32_t)); fill_zero(c, hv.tb.ntl, hv.n * sizeof(uint32_t));
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, hv.tb);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
+	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
+	scan_exclusive_u32_u32(c, hv.tb.ntl, hv.tb.tlbase, hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
+	hv.ntcell = read_back(c, hv.tb.tcbase + hv.n);
+	hv.ntile = read_back(c, hv.tb.tlbase + hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
 }
 
@@ -1213,8 +1415,22 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hipStream_t st = c->stream;
 	CellLists lists;
 	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr);
+	hv.tb.tcells = c->arena.get<TCell>(hv.ntcell ? hv.ntcell : 1);
+	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, hv.tb);
 	SPS_LAUNCH_CHECK();
+	if (hv.ntile > 1) {
+		uint32_t nd = hv.ntile;
+		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
+		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
+		k_tile_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, nd, k0);
+		SPS_LAUNCH_CHECK();
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, 12);
+		Tile *sorted = c->arena.get<Tile>(nd);
+		k_gather_tiles<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, where ? p1 : p0, nd, sorted);
+		SPS_LAUNCH_CHECK();
+		hv.tb.tiles = sorted;
+	}
 	for (int k = 0; k < NCLS; ++k) {
 		uint32_t nd = hv.ncell[k];
 		if (nd < 2) continue;
@@ -1347,7 +1563,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		k_row_cells<<<dim3(grid_for(nb)), dim3(256), 0, st>>>(bins.rows + bins.off[5 + k], nb, rl.beg, rl.id, rprod, segbase, mc.cells[k]);
 		SPS_LAUNCH_CHECK();
 	}
-	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3];
+	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3] + hv.ntcell;
 	res->cells_dense = hv.ncell[CLS_DENSE];
 	res->products_dense = hv.clsprod[CLS_DENSE];
 	SPS_HIP(hipEventRecord(c->ev[2], st));
