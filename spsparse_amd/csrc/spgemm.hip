@@ -1371,6 +1371,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 {
 	hipStream_t st = c->stream;
 	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
+	if (const char *e = getenv("SPSAMD_W")) { int v = atoi(e); if (v == 8192 || v == 16384) hv.W = v; }
 	const uint32_t wshift = hv.W == 8192 ? 13 : 14;
 	hv.nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
 	if (hv.nwin > (uint32_t)WH_MAXW) throw Error{SPSAMD_EINVAL, "too many column windows (ncol > 2^25) for the heavy-row path"};
