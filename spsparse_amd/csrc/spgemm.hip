@@ -184,25 +184,41 @@ __device__ __forceinline__ int bin_of(uint32_t P)
 __global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref,
 	const int32_t *si_pos, const double *si_val, uint32_t *rprod, uint8_t *rbin, BinCounters *bc)
 {
-	// bin statistics are reduced in LDS first: one global atomic per (workgroup, bin)
+	// bin statistics: wave-aggregated (ballot per bin present in the wave), then LDS, then one
+	// global atomic per (workgroup, bin) -- rows of one matrix mostly fall in one bin, so
+	// per-thread atomics on one counter would serialise
 	__shared__ unsigned int s_rows[NBIN];
 	__shared__ unsigned long long s_prods[NBIN];
 	__shared__ unsigned long long s_tuples[NBIN];
 	if (threadIdx.x < NBIN) { s_rows[threadIdx.x] = 0; s_prods[threadIdx.x] = 0; s_tuples[threadIdx.x] = 0; }
 	__syncthreads();
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	int b = -1;
+	uint32_t P = 0, La = 0;
 	if (r < nrows) {
-		uint32_t P = (uint32_t)(pref[beg[r + 1]] - pref[beg[r]]);
+		P = (uint32_t)(pref[beg[r + 1]] - pref[beg[r]]);
+		La = beg[r + 1] - beg[r];
 		if (si_pos) {
 			int32_t q = si_pos[id[r]];
 			if (q < 0 || si_val[q] == 0) P = 0;
 		}
-		int b = bin_of(P);
+		b = bin_of(P);
 		rprod[r] = P;
 		rbin[r] = (uint8_t)b;
-		atomicAdd(&s_rows[b], 1u);
-		atomicAdd(&s_prods[b], (unsigned long long)P);
-		atomicAdd(&s_tuples[b], (unsigned long long)(beg[r + 1] - beg[r]));
+	}
+	uint64_t todo = __ballot(b >= 0);
+	while (todo) {
+		int leader = __ffsll((unsigned long long)todo) - 1;
+		int bb = __shfl(b, leader, 64);
+		uint64_t mine = __ballot(b == bb);
+		unsigned long long p = wave_reduce_sum((unsigned long long)(b == bb ? P : 0u));
+		unsigned long long t = wave_reduce_sum((unsigned long long)(b == bb ? La : 0u));
+		if ((int)lane_id() == leader) {
+			atomicAdd(&s_rows[bb], (unsigned int)__popcll(mine));
+			atomicAdd(&s_prods[bb], p);
+			atomicAdd(&s_tuples[bb], t);
+		}
+		todo &= ~mine;
 	}
 	__syncthreads();
 	if (threadIdx.x < NBIN && s_rows[threadIdx.x]) {
@@ -216,7 +232,8 @@ struct BinOffsets { uint32_t off[NBIN + 1]; };
 
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *rbin, uint32_t nrows, BinOffsets bo, uint32_t *cursor, uint32_t *binrows)
 {
-	// a workgroup reserves one range per bin with a single global atomic
+	// a workgroup reserves one range per bin with a single global atomic; inside it rows are
+	// ranked per wave with ballots (one LDS atomic per wave and bin)
 	__shared__ unsigned int s_cnt[NBIN];
 	__shared__ unsigned int s_base[NBIN];
 	if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
@@ -224,7 +241,17 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *rbin, uint32
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	int b = r < nrows ? rbin[r] : 0;
 	unsigned int local = 0;
-	if (b) local = atomicAdd(&s_cnt[b], 1u);
+	uint64_t todo = __ballot(b != 0);
+	while (todo) {
+		int leader = __ffsll((unsigned long long)todo) - 1;
+		int bb = __shfl(b, leader, 64);
+		uint64_t mine = __ballot(b == bb);
+		unsigned int base = 0;
+		if ((int)lane_id() == leader) base = atomicAdd(&s_cnt[bb], (unsigned int)__popcll(mine));
+		base = (unsigned int)__shfl((int)base, leader, 64);
+		if (b == bb) local = base + (unsigned int)__popcll(mine & lanemask_lt());
+		todo &= ~mine;
+	}
 	__syncthreads();
 	if (threadIdx.x < NBIN && threadIdx.x > 0 && s_cnt[threadIdx.x])
 		s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
