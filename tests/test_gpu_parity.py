@@ -213,7 +213,7 @@ def test_cfg1_1k(ctx):
         assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
 
 
-@pytest.mark.parametrize("scale", [8, 11, 13])
+@pytest.mark.parametrize("scale", [8, 11, 13, 15])
 def test_rmat_full_compare(ctx, scale):
     """R-MAT A*A (cfg2's generator at small scale): all three row classes
     (light / LDS hash / dense windows) against the row-wise oracle, tuple by tuple."""
@@ -226,10 +226,57 @@ def test_rmat_full_compare(ctx, scale):
     assert res.products == res.products_light + res.products_mid + res.products_heavy
     if scale >= 11:
         assert res.rows_heavy > 0 and res.rows_mid > 0 and res.rows_light > 0
+    if scale >= 15:                      # several 8192-column windows: hash cells, tiles and dense cells
+        assert res.cells_hash > 0 and res.cells_dense > 0
     from spsparse_amd import capi
     _, _, _, d = _dev(ctx, A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
     cnt, s, h = orc.digest(*want[:3])
     assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
+
+
+@pytest.mark.parametrize("tA,tB", [(".", "."), ("T", "."), (".", "T"), ("T", "T")])
+def test_heavy_rows_with_scales_and_flags(ctx, tA, tB):
+    """Scale vectors (absent indices, zero scales), C != 1 and 'T' flags on an R-MAT product whose rows
+    reach the LDS-hash, tile and dense-window kernels (the small random cases only reach the light ones)."""
+    rng = np.random.default_rng(5)
+    a = wl.rmat(14, seed=2)          # 16384 columns = two 8192-column windows
+    b = wl.rmat(14, seed=3)
+    n = a[3][0]
+    A, B = orc.Mat(*a), orc.Mat(*b)
+    kw = dict(C_=-2.5, tA=tA, tB=tB, scalei=_rand_vec(rng, n, 0.9), scalej=_rand_vec(rng, n, 0.8), scalek=_rand_vec(rng, n, 0.9))
+    want = orc.multiply(A, B, rowwise=True, nthreads=8, **kw)
+    got = _dev(ctx, A, B, **kw)
+    _check(got, want)
+    assert got[3].rows_heavy > 0 and got[3].cells_hash > 0 and got[3].cells_dense > 0
+    from spsparse_amd import capi
+    _, _, _, d = _dev(ctx, A, B, sink=capi.SINK_DIGEST, **kw)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s_) <= 1e-11 * abs(s_)
+
+
+def test_wide_matrix_16k_windows(ctx):
+    """ncol > 2^21 switches the heavy rows to 16384-column windows (k_dense<16384,1024>): dense cells
+    in a crowded column range, hash cells over the sparse remainder, against the row-wise oracle."""
+    rng = np.random.default_rng(8)
+    m, k, ncol = 6, 96, 1 << 22
+    ai0 = np.repeat(np.arange(m), k)
+    ai1 = np.tile(np.arange(k), m)
+    keep = rng.uniform(size=ai0.size) < 0.8
+    A = orc.Mat(ai0[keep], ai1[keep], rng.uniform(0.1, 1, int(keep.sum())), (m, k))
+    rows, cols = [], []
+    for r in range(k):
+        crowded = rng.integers(0, 90000, 1500)
+        spread = rng.integers(0, ncol, 400)
+        c = np.unique(np.concatenate([crowded, spread]))
+        rows.append(np.full(c.size, r))
+        cols.append(c)
+    bi0, bi1 = np.concatenate(rows), np.concatenate(cols)
+    B = orc.Mat(bi0, bi1, rng.uniform(0.1, 1, bi0.size), (k, ncol))
+    want = orc.multiply(A, B, rowwise=True, nthreads=4)
+    got = _dev(ctx, A, B)
+    _check(got, want)
+    assert got[3].cells_dense > 0 and got[3].cells_hash > 0
+    assert got[3].shape1 == ncol
 
 
 def test_poisson_exact(ctx):
