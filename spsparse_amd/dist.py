@@ -37,15 +37,16 @@ def row_products(a_row, a_col, b_rowlen, n_rows):
     return out
 
 
-def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None):
+def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None, whole_block_fraction=0.5):
     """All-to-allv of the B row panels this rank's A block needs.
 
     a_col           inner indices k of this rank's A block tuples
     b_row/col/val   this rank's own block of B (rows bounds[rank]..bounds[rank+1]), row-major sorted
     bounds          row-block boundaries of B over the inner dimension, len world+1
     Returns (row, col, val) of the received panel: the tuples of every B row
-    this rank needs, sorted row-major (owner blocks arrive in rank order), and
-    the number of tuples received from other ranks.
+    this rank needs (plus, from owners it needs more than `whole_block_fraction`
+    of, their whole block), sorted row-major (owner blocks arrive in rank
+    order), and the number of tuples received from other ranks.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -59,15 +60,27 @@ def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None):
     their_need = torch.empty(my_n * world, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(their_need, need, output_split_sizes=[my_n] * world, input_split_sizes=sizes, group=group)
 
-    # 2. pack, per requester, the tuples of my rows it asked for
+    # 2. pack, per requester, the tuples of my rows it asked for.  A requester that needs most of
+    #    my rows (R-MAT blocks need 80-98 % of B) gets the whole block: no per-tuple selection, and
+    #    rows it did not ask for are simply never referenced by its A block.
     local_row = (b_row.long() - my_lo)
-    sel = [torch.nonzero(their_need[p * my_n:(p + 1) * my_n][local_row], as_tuple=False).flatten() for p in range(world)]
-    send_counts = torch.tensor([s.numel() for s in sel], dtype=torch.int64, device=dev)
+    masks = their_need.view(world, my_n) if my_n else their_need.view(world, 0)
+    frac = (masks.sum(dim=1).to(torch.float64) / max(my_n, 1)).tolist()
+    sel = []
+    for p in range(world):
+        if frac[p] >= whole_block_fraction:
+            sel.append(None)
+        else:
+            sel.append(torch.nonzero(masks[p][local_row], as_tuple=False).flatten())
+    counts = [b_row.numel() if s_ is None else s_.numel() for s_ in sel]
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=dev)
     recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
-    order = torch.cat(sel) if world > 1 else sel[0]
-    s_row, s_col, s_val = b_row[order], b_col[order], b_val[order]
-    in_splits = [int(x) for x in send_counts.tolist()]
+
+    def pack(x):
+        return torch.cat([x if s_ is None else x[s_] for s_ in sel]) if world > 1 else (x if sel[0] is None else x[sel[0]])
+    s_row, s_col, s_val = pack(b_row), pack(b_col), pack(b_val)
+    in_splits = counts
     out_splits = [int(x) for x in recv_counts.tolist()]
     total = sum(out_splits)
 

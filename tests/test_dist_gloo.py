@@ -54,14 +54,22 @@ def _worker(rank, world, port, kind, out_dir):
 
         ma = (a0 >= a_bounds[rank]) & (a0 < a_bounds[rank + 1])
         mb = (b0 >= b_bounds[rank]) & (b0 < b_bounds[rank + 1])
-        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner)
-
-        # the panel holds exactly the B rows this block needs, row-major sorted
+        # exact panels (whole_block_fraction > 1): exactly the B rows this block needs, row-major sorted
+        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner,
+                                                           whole_block_fraction=2.0)
         needed = np.unique(a1[ma])
         want_mask = np.isin(b0, needed)
         assert np.array_equal(r_row.numpy(), b0[want_mask])
         assert np.array_equal(r_col.numpy(), b1[want_mask]) and np.array_equal(r_val.numpy(), bv[want_mask])
         assert remote == int(np.sum(want_mask & ~mb))
+        # default: owners this block needs most of send their whole block -- a sorted superset
+        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner)
+        got_rows = r_row.numpy().astype(np.int64)
+        assert np.all(np.diff(got_rows) >= 0)
+        ncolb = b[3][1]
+        got_keys = got_rows * ncolb + r_col.numpy()
+        want_keys = b0[want_mask].astype(np.int64) * ncolb + b1[want_mask]
+        assert np.all(np.isin(want_keys, got_keys)) and got_keys.size >= want_keys.size
 
         A_blk = orc.Mat(a0[ma], a1[ma], av[ma], a[3], sort0=0)
         B_pan = orc.Mat(r_row.numpy(), r_col.numpy(), r_val.numpy(), b[3], sort0=0)
