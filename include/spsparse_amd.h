@@ -196,6 +196,23 @@ int spsamd_memcpy(spsamd_ctx *ctx, void *dst, const void *src, size_t bytes);
 int spsamd_consolidate(spsamd_ctx *ctx, const spsamd_coo *A, int so0,
 	int duplicate_policy, int zero_nan, spsamd_result *result);
 
+/*
+ * sorted_permutation (algorithm.hpp:411-427): the stable permutation that sorts
+ * the tuples of A by sort_order {so0, 1-so0}; perm_host receives A->nnz entries.
+ * Pinned by tests/test_array.cpp:67-79.
+ */
+int spsamd_sorted_permutation(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uint64_t *perm_host);
+
+/*
+ * dim_beginnings (algorithm.hpp:74-118): offsets at which the leading sorted
+ * index changes, plus the end sentinel -- only non-empty rows appear.  A must
+ * carry sort0 == so0 (the reference raises "dim_beginnings() required the
+ * VectorCooArray is sorted first." otherwise, algorithm.hpp:82-84).
+ * beginnings_host needs room for nnz + 1 entries; *count receives the number
+ * written (0 for an empty array).  Pinned by tests/test_array.cpp:146-166.
+ */
+int spsamd_dim_beginnings(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uint64_t *beginnings_host, size_t *count);
+
 /* ---- synthetic operands generated on the device (bench / tests) ----
  * Bit-identical to spsparse_amd/workloads.py.  Outputs are device arrays
  * owned by the caller (capacity >= the generator's tuple count). */

@@ -57,7 +57,8 @@ CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_
 
 # every symbol include/spsparse_amd.h declares
 SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
-           "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_gen_rmat",
+           "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
+           "spsamd_dim_beginnings", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
 
 _lib = None
@@ -96,6 +97,8 @@ def load():
     L.spsamd_result_fetch.argtypes = [C.c_void_p, P(Result), CHUNK_FN, C.c_void_p]
     L.spsamd_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.spsamd_consolidate.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_int, C.c_int, P(Result)]
+    L.spsamd_sorted_permutation.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_void_p]
+    L.spsamd_dim_beginnings.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_void_p, P(C.c_size_t)]
     L.spsamd_gen_rmat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
     L.spsamd_gen_random_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -178,6 +181,17 @@ class Context:
         res = Result()
         self._check(self.L.spsamd_consolidate(self.h, C.byref(A), so0, duplicate_policy, int(zero_nan), C.byref(res)))
         return res
+
+    def sorted_permutation(self, A, so0):
+        perm = np.zeros(A.nnz, dtype=np.uint64)
+        self._check(self.L.spsamd_sorted_permutation(self.h, C.byref(A), so0, perm.ctypes.data))
+        return perm
+
+    def dim_beginnings(self, A, so0):
+        out = np.zeros(A.nnz + 1, dtype=np.uint64)
+        cnt = C.c_size_t(0)
+        self._check(self.L.spsamd_dim_beginnings(self.h, C.byref(A), so0, out.ctypes.data, C.byref(cnt)))
+        return out[:cnt.value]
 
     def fetch(self, res):
         """Host copy of a SINK_COO result through spsamd_result_fetch: (i, j, v)."""

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <vector>
 
 using namespace spsamd;
 
@@ -240,6 +241,47 @@ extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, i
 		SPS_HIP(hipStreamSynchronize(c->stream));
 		res->nnz = n; res->nnz_a = n;
 		res->idx0 = d0; res->idx1 = d1; res->val = (double *)c->out_v.p;
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_sorted_permutation(spsamd_ctx *c, const spsamd_coo *A, int so0, uint64_t *perm_host)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!A || (so0 != 0 && so0 != 1) || (A->nnz && !perm_host)) throw Error{SPSAMD_EINVAL, "bad argument"};
+		if (A->nnz == 0) return SPSAMD_OK;
+		SPS_HIP(hipSetDevice(c->device));
+		c->arena.reset();
+		uint32_t *perm = sorted_permutation(c, A, so0);
+		std::vector<uint32_t> h(A->nnz);
+		SPS_HIP(hipMemcpyAsync(h.data(), perm, A->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		SPS_HIP(hipStreamSynchronize(c->stream));
+		for (size_t i = 0; i < A->nnz; ++i) perm_host[i] = h[i];
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_dim_beginnings(spsamd_ctx *c, const spsamd_coo *A, int so0, uint64_t *beg_host, size_t *count)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!A || !count || (so0 != 0 && so0 != 1)) throw Error{SPSAMD_EINVAL, "bad argument"};
+		if (A->sort0 != so0) throw Error{SPSAMD_EINVAL, "dim_beginnings() required the VectorCooArray is sorted first."};
+		*count = 0;
+		if (A->nnz == 0) return SPSAMD_OK;                         // algorithm.hpp:89
+		if (!beg_host) throw Error{SPSAMD_EINVAL, "null output"};
+		SPS_HIP(hipSetDevice(c->device));
+		c->arena.reset();
+		ConMat m;
+		consolidate_operand(c, A, so0, SPSAMD_ADD, 0, &m);         // trusted as is (sort0 == so0): upload only
+		RowList rl;
+		dim_beginnings(c, m, &rl);
+		std::vector<uint32_t> h((size_t)rl.nrows + 1);
+		SPS_HIP(hipMemcpyAsync(h.data(), rl.beg, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		SPS_HIP(hipStreamSynchronize(c->stream));
+		for (size_t i = 0; i < h.size(); ++i) beg_host[i] = h[i];
+		*count = h.size();
 		return SPSAMD_OK;
 	)
 }

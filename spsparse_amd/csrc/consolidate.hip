@@ -196,6 +196,26 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int dupli
 	out->nnz = read_back(c, hpos + n);
 }
 
+uint32_t *sorted_permutation(spsamd_ctx *c, const spsamd_coo *X, int lead)
+{
+	size_t n = X->nnz;
+	if (n >= (size_t(1) << 31)) throw Error{SPSAMD_EINVAL, "operand has 2^31 or more tuples"};
+	if (n == 0) return nullptr;
+	if (!X->idx0 || !X->idx1) throw Error{SPSAMD_EINVAL, "operand with nnz > 0 has a null array"};
+	uint64_t shape[2] = {X->shape0, X->shape1};
+	const int32_t *d0 = to_device(c, X->idx0, n, X->mem);
+	const int32_t *d1 = to_device(c, X->idx1, n, X->mem);
+	const int32_t *major = lead == 0 ? d0 : d1;
+	const int32_t *minor = lead == 0 ? d1 : d0;
+	int mb = bits_for(shape[1 - lead]), Mb = bits_for(shape[lead]);
+	uint64_t *keys0 = c->arena.get<uint64_t>(n), *keys1 = c->arena.get<uint64_t>(n);
+	uint32_t *pay0 = c->arena.get<uint32_t>(n), *pay1 = c->arena.get<uint32_t>(n);
+	k_build_keys<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, n, mb, keys0);
+	SPS_LAUNCH_CHECK();
+	int where = radix_sort_pairs(c, keys0, pay0, keys1, pay1, n, mb + Mb);
+	return where ? pay1 : pay0;
+}
+
 // ------------------------------------------------------------------ dim_beginnings
 
 __global__ void k_row_flags(const int32_t *row, size_t n, uint8_t *flag)

@@ -123,6 +123,9 @@ struct RowList {
 };
 void dim_beginnings(spsamd_ctx *c, const ConMat &m, RowList *out);
 
+// Stable permutation sorting X by {lead, 1-lead} (device array of X->nnz uint32, arena memory).
+uint32_t *sorted_permutation(spsamd_ctx *c, const spsamd_coo *X, int lead);
+
 // Dense row pointer over all `nrow + extra` rows (extra trailing empty rows).
 uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra);
 

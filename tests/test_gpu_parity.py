@@ -400,6 +400,30 @@ def test_consolidate_known_answer(ctx):
             assert np.array_equal(gv, wv, equal_nan=True)
 
 
+def test_permutation_and_dim_beginnings_known_answers(ctx):
+    """tests/test_array.cpp:67-79 (sorted_permutation) and :146-166 (dim_beginnings) through the C ABI,
+    then both against the oracle on random inputs (stable order of duplicates included)."""
+    from spsparse_amd import capi
+    s, keep = capi.host_coo([1, 1, 0], [3, 2, 3], [5., 3., 17.], (2, 4))
+    assert ctx.sorted_permutation(s, 0).tolist() == [2, 1, 0]
+    assert ctx.sorted_permutation(s, 1).tolist() == [1, 2, 0]
+    s, keep = capi.host_coo([0, 0, 1, 1], [1, 3, 2, 3], [14., 17., 18., 5.], (2, 4), sort0=0)
+    assert ctx.dim_beginnings(s, 0).tolist() == [0, 2, 4]
+    s, keep = capi.host_coo([0, 1, 0, 1], [1, 2, 3, 3], [14., 18., 17., 5.], (2, 4), sort0=1)
+    assert ctx.dim_beginnings(s, 1).tolist() == [0, 1, 2, 4]
+    with pytest.raises(capi.SpsamdError, match="sorted first"):
+        ctx.dim_beginnings(capi.host_coo([0], [0], [1.], (1, 1))[0], 0)
+    rng = np.random.default_rng(2)
+    i0, i1 = rng.integers(0, 300, 20000), rng.integers(0, 40, 20000)
+    v = rng.uniform(size=20000)
+    for so0 in (0, 1):
+        s, keep = capi.host_coo(i0, i1, v, (300, 40))
+        assert np.array_equal(ctx.sorted_permutation(s, so0), orc.sorted_permutation(i0, i1, so0))
+        c0, c1, cv = orc.consolidate(i0, i1, v, so0)
+        s, keep = capi.host_coo(c0, c1, cv, (300, 40), sort0=so0)
+        assert np.array_equal(ctx.dim_beginnings(s, so0), orc.dim_beginnings(c0 if so0 == 0 else c1))
+
+
 def test_device_generators_match_numpy(ctx):
     """csrc/workload.hip == spsparse_amd/workloads.py, tuple for tuple."""
     import torch
