@@ -119,6 +119,7 @@ typedef struct {
 	uint32_t pad_;
 	uint64_t cells_hash, cells_dense;   /* heavy rows are cut into cells: LDS-hash cells and dense-window cells */
 	uint64_t products_dense;            /* products of the dense-window cells (part of products_heavy) */
+	uint64_t workspace_bytes;           /* device workspace this call carved from the context's arena */
 	uint64_t rows_light, rows_mid, rows_heavy;
 	uint64_t products_light, products_mid, products_heavy;
 	uint64_t tuples_light, tuples_mid, tuples_heavy;      /* A tuples in the rows of each class */

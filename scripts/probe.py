@@ -66,10 +66,10 @@ def main():
         r = ctx.multiply(A, A, sink=sink)
         dt = time.time() - t
         print("%s %d rep %d: total %.1f ms (cons %.1f symb %.1f light %.2f mid %.2f hash %.1f dense %.1f) "
-              "P %.3g nnzC %.3g | prods mid %.3g hash %.3g dense %.3g | cells hash %d dense %d | %.3g prod/s, %.0f GB/s alg-read" % (
+              "P %.3g nnzC %.3g | prods mid %.3g hash %.3g dense %.3g | cells hash %d dense %d | ws %.2f GB | %.3g prod/s, %.0f GB/s alg-read" % (
                   kind, size, rep, r.ms_total, r.ms_consolidate, r.ms_symbolic, r.ms_light, r.ms_mid, r.ms_heavy - r.ms_dense,
                   r.ms_dense, r.products, r.nnz, r.products_mid, r.products_heavy - r.products_dense, r.products_dense,
-                  r.cells_hash, r.cells_dense, r.products / (r.ms_total * 1e-3),
+                  r.cells_hash, r.cells_dense, r.workspace_bytes / 1e9, r.products / (r.ms_total * 1e-3),
                   (16 * r.nnz_a + 12 * r.products) / (r.ms_total * 1e-3) / 1e9), flush=True)
 
 

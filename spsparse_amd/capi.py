@@ -47,7 +47,7 @@ class Result(C.Structure):
                 ("row_nnz", C.c_void_p), ("row_sum", C.c_void_p),
                 ("ms_consolidate", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float),
                 ("ms_total", C.c_float), ("ms_light", C.c_float), ("ms_mid", C.c_float), ("ms_heavy", C.c_float),
-                ("ms_dense", C.c_float), ("pad_", C.c_uint32), ("cells_hash", C.c_uint64), ("cells_dense", C.c_uint64), ("products_dense", C.c_uint64),
+                ("ms_dense", C.c_float), ("pad_", C.c_uint32), ("cells_hash", C.c_uint64), ("cells_dense", C.c_uint64), ("products_dense", C.c_uint64), ("workspace_bytes", C.c_uint64),
                 ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
                 ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64),
                 ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64)]

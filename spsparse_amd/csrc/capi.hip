@@ -126,6 +126,7 @@ static int multiply_body(spsamd_ctx *c, double C,
 		SPS_HIP(hipEventElapsedTime(&res->ms_consolidate, c->ev[0], c->ev[1]));
 	}
 	SPS_HIP(hipEventElapsedTime(&res->ms_total, c->ev[0], c->ev[7]));
+	res->workspace_bytes = c->arena.call_used;
 	return SPSAMD_OK;
 }
 
