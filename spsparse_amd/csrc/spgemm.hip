@@ -267,7 +267,7 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 
 // One wave handles G = 64/S rows, S product slots each.
 template <int S, int MODE>
-__global__ __launch_bounds__(256) void k_light(const uint32_t *binrows, uint32_t nbin, RowMeta m, EmitParams ep, SinkParams sk)
+__global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint32_t nbin, RowMeta m, EmitParams ep, SinkParams sk)
 {
 	constexpr int G = 64 / S;
 	__shared__ uint32_t s_apos[4][64];
