@@ -36,6 +36,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
 	return (uint32_t)x;
 }
 
+// Inclusive scan inside aligned groups of S lanes (S = 8, 16, 32, 64), DPP only.
+// s = lane index inside the group.
+template <int S>
+__device__ __forceinline__ uint32_t group_inclusive_scan_u32(uint32_t v, unsigned s)
+{
+	int x = (int)v, t;
+	t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); if (s >= 1) x += t;      // row_shr:1 (rows of 16 lanes)
+	t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); if (s >= 2) x += t;
+	t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); if (s >= 4) x += t;
+	if (S >= 16) { t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); if (s >= 8) x += t; }
+	if (S >= 32) { t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); if (s >= 16) x += t; }   // row_bcast:15
+	if (S >= 64) { t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); if (s >= 32) x += t; }   // row_bcast:31
+	return (uint32_t)x;
+}
+
 template <class T>
 __device__ __forceinline__ T wave_reduce_sum(T v)
 {

@@ -287,21 +287,14 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 	const uint32_t end = has_row ? m.beg[r + 1] : 0u;
 
 	// ---- expand: slot t of the row's P products -> (A tuple, B tuple)
-	uint32_t La = end - beg, maxLa = La;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) maxLa = max(maxLa, (uint32_t)__shfl_xor((int)maxLa, d, 64));
+	const uint32_t La = end - beg;
 	uint32_t off = 0;
-	for (uint32_t base = 0; base < maxLa; base += S) {
+	for (uint32_t base = 0; __any(base < La); base += S) {
 		uint32_t e = beg + base + s;
 		bool act = has_row && e < end;
 		uint32_t lo = 0, len = 0;
 		if (act) { lo = m.elo[e]; len = m.elen[e]; }
-		uint32_t inc = len;
-#pragma unroll
-		for (int d = 1; d < S; d <<= 1) {
-			uint32_t o = (uint32_t)__shfl_up((int)inc, d, S);
-			if ((int)s >= d) inc += o;
-		}
+		const uint32_t inc = group_inclusive_scan_u32<S>(len, s);
 		uint32_t ex = off + inc - len;
 		for (uint32_t t = 0; t < len; ++t) {        // ex + t < S because P_r <= S
 			s_apos[w][g * S + ex + t] = e;
