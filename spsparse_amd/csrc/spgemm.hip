@@ -181,44 +181,51 @@ __device__ __forceinline__ int bin_of(uint32_t P)
 // Per non-empty A row: product count and bin.  scalei (multiply_sparse.hpp:195
 // and the Join2 of ScaledMultXiter :79-86): a row absent from the vector, or
 // whose scale is 0, is skipped.
-__global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref,
+constexpr int CLS_ITEMS = 16;                   // rows per thread: few workgroups -> few same-address global atomics
+
+__global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref, const uint32_t *elen,
 	const int32_t *si_pos, const double *si_val, uint32_t *rprod, uint8_t *rbin, BinCounters *bc)
 {
 	// bin statistics: wave-aggregated (ballot per bin present in the wave), then LDS, then one
-	// global atomic per (workgroup, bin) -- rows of one matrix mostly fall in one bin, so
-	// per-thread atomics on one counter would serialise
+	// global atomic per (workgroup, bin).  Same-address global atomics serialise (~5 ns each), so
+	// a workgroup covers 256 * CLS_ITEMS rows.
 	__shared__ unsigned int s_rows[NBIN];
 	__shared__ unsigned long long s_prods[NBIN];
 	__shared__ unsigned long long s_tuples[NBIN];
 	if (threadIdx.x < NBIN) { s_rows[threadIdx.x] = 0; s_prods[threadIdx.x] = 0; s_tuples[threadIdx.x] = 0; }
 	__syncthreads();
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	int b = -1;
-	uint32_t P = 0, La = 0;
-	if (r < nrows) {
-		P = (uint32_t)(pref[beg[r + 1]] - pref[beg[r]]);
-		La = beg[r + 1] - beg[r];
-		if (si_pos) {
-			int32_t q = si_pos[id[r]];
-			if (q < 0 || si_val[q] == 0) P = 0;
+	for (int it = 0; it < CLS_ITEMS; ++it) {
+		uint32_t r = (blockIdx.x * CLS_ITEMS + it) * 256u + threadIdx.x;
+		int b = -1;
+		uint32_t P = 0, La = 0;
+		if (r < nrows) {
+			const uint32_t b0 = beg[r], b1 = beg[r + 1];
+			La = b1 - b0;
+			if (La <= 8) {                          // short row: its tuples' lengths are one or two cache lines
+				for (uint32_t e = b0; e < b1; ++e) P += elen[e];
+			} else P = (uint32_t)(pref[b1] - pref[b0]);
+			if (si_pos) {
+				int32_t q = si_pos[id[r]];
+				if (q < 0 || si_val[q] == 0) P = 0;
+			}
+			b = bin_of(P);
+			rprod[r] = P;
+			rbin[r] = (uint8_t)b;
 		}
-		b = bin_of(P);
-		rprod[r] = P;
-		rbin[r] = (uint8_t)b;
-	}
-	uint64_t todo = __ballot(b >= 0);
-	while (todo) {
-		int leader = __ffsll((unsigned long long)todo) - 1;
-		int bb = __shfl(b, leader, 64);
-		uint64_t mine = __ballot(b == bb);
-		unsigned long long p = wave_reduce_sum((unsigned long long)(b == bb ? P : 0u));
-		unsigned long long t = wave_reduce_sum((unsigned long long)(b == bb ? La : 0u));
-		if ((int)lane_id() == leader) {
-			atomicAdd(&s_rows[bb], (unsigned int)__popcll(mine));
-			atomicAdd(&s_prods[bb], p);
-			atomicAdd(&s_tuples[bb], t);
+		uint64_t todo = __ballot(b >= 0);
+		while (todo) {
+			int leader = __ffsll((unsigned long long)todo) - 1;
+			int bb = __shfl(b, leader, 64);
+			uint64_t mine = __ballot(b == bb);
+			unsigned long long p = wave_reduce_sum((unsigned long long)(b == bb ? P : 0u));
+			unsigned long long t = wave_reduce_sum((unsigned long long)(b == bb ? La : 0u));
+			if ((int)lane_id() == leader) {
+				atomicAdd(&s_rows[bb], (unsigned int)__popcll(mine));
+				atomicAdd(&s_prods[bb], p);
+				atomicAdd(&s_tuples[bb], t);
+			}
+			todo &= ~mine;
 		}
-		todo &= ~mine;
 	}
 	__syncthreads();
 	if (threadIdx.x < NBIN && s_rows[threadIdx.x]) {
@@ -232,31 +239,42 @@ struct BinOffsets { uint32_t off[NBIN + 1]; };
 
 __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *rbin, uint32_t nrows, BinOffsets bo, uint32_t *cursor, uint32_t *binrows)
 {
-	// a workgroup reserves one range per bin with a single global atomic; inside it rows are
-	// ranked per wave with ballots (one LDS atomic per wave and bin)
+	// a workgroup (256 * CLS_ITEMS rows) reserves one range per bin with a single global atomic;
+	// inside it rows are ranked per wave with ballots (one LDS atomic per wave, bin and step)
 	__shared__ unsigned int s_cnt[NBIN];
 	__shared__ unsigned int s_base[NBIN];
 	if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	int b = r < nrows ? rbin[r] : 0;
-	unsigned int local = 0;
-	uint64_t todo = __ballot(b != 0);
-	while (todo) {
-		int leader = __ffsll((unsigned long long)todo) - 1;
-		int bb = __shfl(b, leader, 64);
-		uint64_t mine = __ballot(b == bb);
-		unsigned int base = 0;
-		if ((int)lane_id() == leader) base = atomicAdd(&s_cnt[bb], (unsigned int)__popcll(mine));
-		base = (unsigned int)__shfl((int)base, leader, 64);
-		if (b == bb) local = base + (unsigned int)__popcll(mine & lanemask_lt());
-		todo &= ~mine;
+	unsigned int local[CLS_ITEMS];
+	uint8_t bins[CLS_ITEMS];
+#pragma unroll
+	for (int it = 0; it < CLS_ITEMS; ++it) {
+		uint32_t r = (blockIdx.x * CLS_ITEMS + it) * 256u + threadIdx.x;
+		int b = r < nrows ? rbin[r] : 0;
+		unsigned int loc = 0;
+		uint64_t todo = __ballot(b != 0);
+		while (todo) {
+			int leader = __ffsll((unsigned long long)todo) - 1;
+			int bb = __shfl(b, leader, 64);
+			uint64_t mine = __ballot(b == bb);
+			unsigned int base = 0;
+			if ((int)lane_id() == leader) base = atomicAdd(&s_cnt[bb], (unsigned int)__popcll(mine));
+			base = (unsigned int)__shfl((int)base, leader, 64);
+			if (b == bb) loc = base + (unsigned int)__popcll(mine & lanemask_lt());
+			todo &= ~mine;
+		}
+		local[it] = loc; bins[it] = (uint8_t)b;
 	}
 	__syncthreads();
 	if (threadIdx.x < NBIN && threadIdx.x > 0 && s_cnt[threadIdx.x])
 		s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
 	__syncthreads();
-	if (b) binrows[bo.off[b] + s_base[b] + local] = r;
+#pragma unroll
+	for (int it = 0; it < CLS_ITEMS; ++it) {
+		uint32_t r = (blockIdx.x * CLS_ITEMS + it) * 256u + threadIdx.x;
+		int b = bins[it];
+		if (b) binrows[bo.off[b] + s_base[b] + local[it]] = r;
+	}
 }
 
 // ====================================================================== light rows
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 	const unsigned g = lane / S, s = lane % S;
 	const uint32_t rix = (blockIdx.x * 4u + w) * G + g;
 	const bool has_row = rix < nbin;
-	const uint32_t r = has_row ? binrows[rix] : 0u;
+	const uint32_t r = has_row ? (binrows ? binrows[rix] : rix) : 0u;      // null list: the bin holds every row
 	const uint32_t beg = has_row ? m.beg[r] : 0u;
 	const uint32_t end = has_row ? m.beg[r + 1] : 0u;
 
@@ -1292,10 +1310,10 @@ template <int MODE>
 static void launch_light(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	hipStream_t st = c->stream;
-	if (b.count[1]) { k_light<8, MODE><<<dim3(grid_for(b.count[1], 32)), dim3(256), 0, st>>>(b.rows + b.off[1], b.count[1], m, ep, sk); SPS_LAUNCH_CHECK(); }
-	if (b.count[2]) { k_light<16, MODE><<<dim3(grid_for(b.count[2], 16)), dim3(256), 0, st>>>(b.rows + b.off[2], b.count[2], m, ep, sk); SPS_LAUNCH_CHECK(); }
-	if (b.count[3]) { k_light<32, MODE><<<dim3(grid_for(b.count[3], 8)), dim3(256), 0, st>>>(b.rows + b.off[3], b.count[3], m, ep, sk); SPS_LAUNCH_CHECK(); }
-	if (b.count[4]) { k_light<64, MODE><<<dim3(grid_for(b.count[4], 4)), dim3(256), 0, st>>>(b.rows + b.off[4], b.count[4], m, ep, sk); SPS_LAUNCH_CHECK(); }
+	if (b.count[1]) { k_light<8, MODE><<<dim3(grid_for(b.count[1], 32)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[1] : nullptr, b.count[1], m, ep, sk); SPS_LAUNCH_CHECK(); }
+	if (b.count[2]) { k_light<16, MODE><<<dim3(grid_for(b.count[2], 16)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[2] : nullptr, b.count[2], m, ep, sk); SPS_LAUNCH_CHECK(); }
+	if (b.count[3]) { k_light<32, MODE><<<dim3(grid_for(b.count[3], 8)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[3] : nullptr, b.count[3], m, ep, sk); SPS_LAUNCH_CHECK(); }
+	if (b.count[4]) { k_light<64, MODE><<<dim3(grid_for(b.count[4], 4)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[4] : nullptr, b.count[4], m, ep, sk); SPS_LAUNCH_CHECK(); }
 }
 
 template <int T, int NT, int MODE, bool WINDOWED>
@@ -1518,7 +1536,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	uint8_t *rbin = c->arena.get<uint8_t>(rl.nrows);
 	BinCounters *bc = c->arena.get<BinCounters>(1);
 	fill_zero(c, bc, sizeof(BinCounters));
-	k_classify<<<dim3(grid_for(rl.nrows)), dim3(256), 0, st>>>(rl.beg, rl.id, rl.nrows, pref,
+	k_classify<<<dim3(grid_for(rl.nrows, 256 * CLS_ITEMS)), dim3(256), 0, st>>>(rl.beg, rl.id, rl.nrows, pref, elen,
 		a.si.present ? a.si.pos : nullptr, a.si.val, rprod, rbin, bc);
 	SPS_LAUNCH_CHECK();
 	BinCounters hbc = read_back(c, bc);
@@ -1532,11 +1550,16 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		run += bins.count[b];
 	}
 	bins.off[NBIN] = bo.off[NBIN] = run;
-	bins.rows = c->arena.get<uint32_t>(run ? run : 1);
-	uint32_t *cursor = c->arena.get<uint32_t>(NBIN);
-	fill_zero(c, cursor, NBIN * sizeof(uint32_t));
-	k_bin_scatter<<<dim3(grid_for(rl.nrows)), dim3(256), 0, st>>>(rbin, rl.nrows, bo, cursor, bins.rows);
-	SPS_LAUNCH_CHECK();
+	int whole_bin = 0;                               // a light bin that holds every row needs no list
+	for (int b = 1; b <= 4; ++b) if (bins.count[b] == rl.nrows) whole_bin = b;
+	bins.rows = nullptr;
+	if (!whole_bin) {
+		bins.rows = c->arena.get<uint32_t>(run ? run : 1);
+		uint32_t *cursor = c->arena.get<uint32_t>(NBIN);
+		fill_zero(c, cursor, NBIN * sizeof(uint32_t));
+		k_bin_scatter<<<dim3(grid_for(rl.nrows, 256 * CLS_ITEMS)), dim3(256), 0, st>>>(rbin, rl.nrows, bo, cursor, bins.rows);
+		SPS_LAUNCH_CHECK();
+	}
 
 	uint64_t P = 0;
 	for (int b = 1; b < NBIN; ++b) P += hbc.prods[b];
