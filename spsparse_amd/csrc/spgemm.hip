@@ -956,7 +956,16 @@ __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint3
 	} else {
 		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) {
 			uint32_t cnt = 0;
-			for (uint32_t e = beg; e < end; ++e) {
+			uint32_t e = beg;
+			for (; e + 3 < end; e += 4) {               // four index rows in flight
+				const uint32_t *b0 = bwin + (uint64_t)m.acol[e] * nwin1 + w;
+				const uint32_t *b1 = bwin + (uint64_t)m.acol[e + 1] * nwin1 + w;
+				const uint32_t *b2 = bwin + (uint64_t)m.acol[e + 2] * nwin1 + w;
+				const uint32_t *b3 = bwin + (uint64_t)m.acol[e + 3] * nwin1 + w;
+				uint32_t x0 = b0[0], y0 = b0[1], x1 = b1[0], y1 = b1[1], x2 = b2[0], y2 = b2[1], x3 = b3[0], y3 = b3[1];
+				cnt += (y0 - x0) + (y1 - x1) + (y2 - x2) + (y3 - x3);
+			}
+			for (; e < end; ++e) {
 				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
 				cnt += bw[w + 1] - bw[w];
 			}
