@@ -136,7 +136,7 @@ def main():
         c0, c1, cv = consolidated(capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n)))
         rowlen = torch.bincount(c0.long(), minlength=n)
         P = sd.row_products(c0, c1, rowlen, n)
-        bounds = sd.product_balanced_bounds(P, world)
+        bounds = sd.product_balanced_bounds(sd.row_cost(P), world)     # blocks equal in estimated time
         del c0, c1, cv, P, rowlen
         keep = (raw0 >= bounds[rank]) & (raw0 < bounds[rank + 1])
         blk0, blk1, blkv = raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
@@ -224,7 +224,7 @@ def main():
                 "workload": "R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
                             "raw COO tuples resident in HBM, digest sink" % (scale, seed),
                 "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
-                "parallelism": "1 GPU" if world == 1 else "%d row blocks (product balanced) + all-to-allv of B row panels" % world,
+                "parallelism": "1 GPU" if world == 1 else "%d row blocks (balanced by per-row cost estimate) + all-to-allv of B row panels" % world,
                 "remote_panel_tuples": remote_total,
                 "digest": {"sum": vsum, "hash": "%016x" % vhash},
                 "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,

@@ -16,8 +16,9 @@ import torch.distributed as dist
 
 def product_balanced_bounds(row_products, nparts):
     """Contiguous row-block boundaries [b0=0, b1, ..., bN=n] such that every
-    block holds ~1/nparts of the scalar products (equal-size blocks put 40% of
-    an un-permuted R-MAT's products on shard 0).  row_products: int64 [n]."""
+    block holds ~1/nparts of the given per-row weights: the scalar products, or
+    row_cost() of them (equal-size blocks put 40% of an un-permuted R-MAT's
+    products on shard 0).  row_products: int64 [n]."""
     n = row_products.numel()
     pref = torch.cumsum(row_products.to(torch.int64), 0)
     total = int(pref[-1]) if n else 0
@@ -28,6 +29,24 @@ def product_balanced_bounds(row_products, nparts):
     for q in range(1, len(b)):          # monotone
         b[q] = max(b[q], b[q - 1])
     return b
+
+
+# Measured device time per scalar product by the size of its output row (MI355X, R-MAT scale-20
+# sharded 8 ways, scripts/sim_shards.py): light rows (<= 64 products) ~16 ps, rows of one hash
+# cell (<= 4096) ~10 ps, the bulk ~4.8 ps; rows beyond a million products cost more again
+# (~7 ps): their largest dense cells are single work items that finish last on a small shard.
+_COST_STEPS = ((64, 16.0), (4096, 10.0), (1 << 20, 4.8))
+_COST_TOP = 7.0
+
+
+def row_cost(row_products_):
+    """Estimated device time (ps) of every output row from its product count: the weights that
+    make the contiguous row blocks equal in TIME, not just in products."""
+    P = row_products_.to(torch.float64)
+    w = torch.full_like(P, _COST_TOP)
+    for limit, cost in reversed(_COST_STEPS):
+        w = torch.where(P <= limit, torch.full_like(P, cost), w)
+    return (P * w).round().to(torch.int64)
 
 
 def row_products(a_row, a_col, b_rowlen, n_rows):

@@ -104,6 +104,14 @@ def test_row_block_sharding_world2(tmp_path, kind):
         assert abs(float(p["tots"][0]) - s) <= 1e-12 * abs(s)
 
 
+def test_row_cost_weights():
+    P = torch.tensor([0, 10, 64, 65, 4096, 4097, 70000, 2000000], dtype=torch.int64)
+    c = sd.row_cost(P)
+    assert c.tolist() == [0, 160, 1024, 650, 40960, 19666, 336000, 14000000]
+    b = sd.product_balanced_bounds(c, 2)
+    assert b[0] == 0 and b[-1] == 8 and 0 < b[1] <= 8
+
+
 def test_balanced_bounds_edge_cases():
     P = torch.tensor([0, 0, 10, 0, 5, 5, 0], dtype=torch.int64)
     b = sd.product_balanced_bounds(P, 2)
