@@ -81,8 +81,6 @@ struct RowMeta {
 	const int32_t *acol;            // A tuples: inner index k
 	const double *aval;             // A tuples: value (already times scalej)
 	const uint32_t *bptr;           // B dense row pointer
-	const int32_t *bcol;
-	const double *bval;
 	const BTup *btup;               // B tuples, (col, val) interleaved
 	const uint32_t *elo;            // A tuples: first B tuple of the selected row (bptr[k])
 	const uint32_t *elen;           // A tuples: length of the selected B row
@@ -1586,7 +1584,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	BTup *btup = c->arena.get<BTup>(B.nnz);
 	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
 	SPS_LAUNCH_CHECK();
-	RowMeta m{rl.beg, rl.id, acol, aval, bptr, B.col, B.val, btup, elo, elen};
+	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
 		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0};
 
