@@ -182,6 +182,19 @@ typedef int (*spsamd_chunk_fn)(void *user, const int32_t *i, const int32_t *j,
 int spsamd_result_fetch(spsamd_ctx *ctx, const spsamd_result *result,
 	spsamd_chunk_fn cb, void *user);
 
+/*
+ * DenseAccum (accum.hpp:110-140) on the device: apply the tuples of a SINK_COO
+ * result to a row-major dense matrix in device memory,
+ *     dense[i * ld + j]  (op)=  v        per duplicate_policy
+ * ADD sums into the existing entry, REPLACE overwrites it, LEAVE_ALONE writes
+ * only where the entry is still exactly 0 (the first value stays).  The
+ * reference's LEAVE_ALONE branch tests !isnan(oval) and then overwrites
+ * (accum.hpp:129-131, SURVEY Appendix A.12: looks inverted); the documented
+ * meaning of the policy (spsparse.hpp:19-23) is implemented instead.
+ */
+int spsamd_result_scatter_dense(spsamd_ctx *ctx, const spsamd_result *result, double *dense_device, size_t ld,
+	int duplicate_policy);
+
 /* Copy `bytes` between host and/or device memory of this context's device
  * (e.g. result->row_nnz to the host, result->idx0 into a caller's device
  * buffer), ordered after everything queued on the context's stream; returns

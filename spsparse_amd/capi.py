@@ -57,7 +57,7 @@ CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_
 
 # every symbol include/spsparse_amd.h declares
 SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
-           "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
+           "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_result_scatter_dense", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
            "spsamd_dim_beginnings", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
 
@@ -95,6 +95,7 @@ def load():
     L.spsamd_multiply_mv.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Vec),
                                      C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_result_fetch.argtypes = [C.c_void_p, P(Result), CHUNK_FN, C.c_void_p]
+    L.spsamd_result_scatter_dense.argtypes = [C.c_void_p, P(Result), C.c_void_p, C.c_size_t, C.c_int]
     L.spsamd_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.spsamd_consolidate.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_sorted_permutation.argtypes = [C.c_void_p, P(Coo), C.c_int, C.c_void_p]
@@ -210,6 +211,10 @@ class Context:
         self._check(self.L.spsamd_result_fetch(self.h, C.byref(res), CHUNK_FN(cb), None))
         assert pos[0] == n
         return oi, oj, ov
+
+    def scatter_dense(self, res, dense_ptr, ld, duplicate_policy=ADD):
+        """DenseAccum on the device: dense[i*ld + j] (+)= v for the tuples of a SINK_COO result."""
+        self._check(self.L.spsamd_result_scatter_dense(self.h, C.byref(res), dense_ptr, ld, duplicate_policy))
 
     def to_host(self, dev_ptr, count, dtype):
         """numpy copy of `count` elements of device memory (spsamd_memcpy)."""

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <vector>
 
@@ -200,6 +201,35 @@ extern "C" int spsamd_result_fetch(spsamd_ctx *c, const spsamd_result *res, spsa
 			int rc = cb(user, hi, res->idx1 ? hj : nullptr, hv, n);
 			if (rc) return rc;
 		}
+		return SPSAMD_OK;
+	)
+}
+
+__global__ void k_scatter_dense(const int32_t *i, const int32_t *j, const double *v, uint64_t n, double *dense, size_t ld, int policy)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; t < n; t += stride) {
+		double *p = dense + (size_t)i[t] * ld + (size_t)j[t];      // (i, j) is unique inside one result
+		if (policy == SPSAMD_ADD) *p += v[t];
+		else if (policy == SPSAMD_REPLACE) *p = v[t];
+		else if (*p == 0) *p = v[t];
+	}
+}
+
+extern "C" int spsamd_result_scatter_dense(spsamd_ctx *c, const spsamd_result *res, double *dense, size_t ld, int policy)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!res || (res->nnz && (!dense || !res->idx0 || !res->idx1 || !res->val))) throw Error{SPSAMD_EINVAL, "null result, matrix or no COO tuples"};
+		if (policy < 0 || policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+		if (ld < res->shape1) throw Error{SPSAMD_EINVAL, "leading dimension smaller than the result's column count"};
+		if (res->nnz == 0) return SPSAMD_OK;
+		SPS_HIP(hipSetDevice(c->device));
+		unsigned grid = (unsigned)std::min<uint64_t>((res->nnz + 255) / 256, 8192);
+		k_scatter_dense<<<dim3(grid), dim3(256), 0, c->stream>>>(res->idx0, res->idx1, res->val, res->nnz, dense, ld, policy);
+		SPS_LAUNCH_CHECK();
+		SPS_HIP(hipStreamSynchronize(c->stream));
 		return SPSAMD_OK;
 	)
 }

@@ -424,6 +424,30 @@ def test_permutation_and_dim_beginnings_known_answers(ctx):
         assert np.array_equal(ctx.dim_beginnings(s, so0), orc.dim_beginnings(c0 if so0 == 0 else c1))
 
 
+def test_dense_accumulator_sink(ctx):
+    """DenseAccum analogue (accum.hpp:110-140): the COO result scattered into a device dense matrix,
+    ADD twice (the sink is appended to, never cleared) then REPLACE, against the oracle's tuples."""
+    import torch
+    from spsparse_amd import capi
+    rng = np.random.default_rng(4)
+    A, B = _rand_mat(rng, (37, 50), 400), _rand_mat(rng, (50, 41), 500)
+    wi, wj, wv, _ = orc.multiply(A, B)
+    want = np.zeros((37, 41))
+    want[wi, wj] = wv
+    a, ka = capi.host_coo(A.idx0, A.idx1, A.val, A.shape)
+    b, kb = capi.host_coo(B.idx0, B.idx1, B.val, B.shape)
+    res = ctx.multiply(a, b, sink=capi.SINK_COO)
+    dense = torch.zeros((37, 48), dtype=torch.float64, device="cuda:0")     # ld = 48 > 41 columns
+    ctx.scatter_dense(res, dense.data_ptr(), 48, capi.ADD)
+    ctx.scatter_dense(res, dense.data_ptr(), 48, capi.ADD)
+    got = dense.cpu().numpy()
+    assert np.allclose(got[:, :41], 2 * want, rtol=1e-12, atol=0) and not got[:, 41:].any()
+    ctx.scatter_dense(res, dense.data_ptr(), 48, capi.REPLACE)
+    assert np.allclose(dense.cpu().numpy()[:, :41], want, rtol=1e-12, atol=0)
+    with pytest.raises(capi.SpsamdError, match="leading dimension"):
+        ctx.scatter_dense(res, dense.data_ptr(), 40)
+
+
 def test_device_generators_match_numpy(ctx):
     """csrc/workload.hip == spsparse_amd/workloads.py, tuple for tuple."""
     import torch
