@@ -53,6 +53,11 @@ inline void default_error(int retcode, const char *format, ...)
 inline error_ptr spsparse_error = &default_error;
 
 // spsparse.cpp:30-31
+// SPSAMD_SINK_* flags passed to every multiply of this process.  Set to SPSAMD_SINK_ORDERED to have
+// every sum accumulated in ascending k exactly like multiply_sparse.hpp:219-236 (bit-identical results
+// on any input; the default is within 1e-12 relative and bit-identical on rows of <= 64 products).
+inline int multiply_flags = 0;
+
 inline const std::array<int, 2> ROW_MAJOR = {0, 1};
 inline const std::array<int, 2> COL_MAJOR = {1, 0};
 
@@ -246,7 +251,7 @@ void multiply(
 	if (!ctx) return;
 	spsamd_result res;
 	int rc = spsamd_multiply(ctx, C, scalei ? &si : nullptr, &a, transpose_A, scalej ? &sj : nullptr, &b, transpose_B,
-		scalek ? &sk : nullptr, (int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, 0, &res);
+		scalek ? &sk : nullptr, (int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, multiply_flags, &res);
 	if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
 	rc = spsamd_result_fetch(ctx, &res, &detail::add_chunk<AccumulatorT>, &ret);
 	if (rc != 0) (*spsparse_error)(-1, "%s", spsamd_last_error(ctx));
@@ -288,7 +293,7 @@ void multiply(
 	if (!ctx) return;
 	spsamd_result res;
 	int rc = spsamd_multiply_mv(ctx, C, scalei ? &si : nullptr, &a, transpose_A, scalej ? &sj : nullptr, &v,
-		(int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, 0, &res);
+		(int)duplicate_policy, zero_nan ? 1 : 0, SPSAMD_SINK_COO, multiply_flags, &res);
 	if (rc != 0) { (*spsparse_error)(-1, "%s", spsamd_last_error(ctx)); return; }
 	rc = spsamd_result_fetch(ctx, &res, &add_chunk_v<AccumulatorT>, &ret);
 	if (rc != 0) (*spsparse_error)(-1, "%s", spsamd_last_error(ctx));

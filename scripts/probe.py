@@ -1,4 +1,5 @@
 """Developer probe: time the device pipeline on a synthetic operand (not the bench)."""
+import os
 import sys
 import time
 
@@ -63,7 +64,7 @@ def main():
     A = capi.device_coo(t0.data_ptr(), t1.data_ptr(), tv.data_ptr(), ne, (n, n))
     for rep in range(reps):
         t = time.time()
-        r = ctx.multiply(A, A, sink=sink)
+        r = ctx.multiply(A, A, sink=sink, flags=int(os.environ.get("PROBE_FLAGS", "0")))
         dt = time.time() - t
         print("%s %d rep %d: total %.1f ms (cons %.1f symb %.1f light %.2f mid %.2f hash %.1f dense %.1f) "
               "P %.3g nnzC %.3g | prods mid %.3g hash %.3g dense %.3g | cells hash %d dense %d | ws %.2f GB | %.3g prod/s, %.0f GB/s alg-read" % (

@@ -17,6 +17,7 @@ LEAVE_ALONE, ADD, REPLACE = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 SINK_COO, SINK_DIGEST = 1, 2
 SINK_ROWSTATS = 1
+SINK_ORDERED = 2
 
 ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE"}
 

@@ -46,6 +46,7 @@ struct EmitParams {
 	const int32_t *si_pos; const double *si_val;     // row scale (null: none)
 	const int32_t *sk_pos; const double *sk_val;     // column scale (null: none)
 	int dbg;                                         // developer ablation switches (0 in production)
+	int ordered;                                     // SPSAMD_SINK_ORDERED: ascending-k sums everywhere (bit-exact)
 };
 
 struct DigestSlot { unsigned long long count; unsigned long long hash; double sum; unsigned long long pad; };
@@ -608,6 +609,48 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 	}
 }
 
+// SPSAMD_SINK_ORDERED: the segments [q0, q1) of the prepared chunk one after the other, in
+// ascending k.  Inside one segment the columns are unique (B is consolidated), so the threads
+// update distinct slots with plain read-modify-writes; a barrier separates the segments.  Every
+// sum is then accumulated exactly like the reference's `sum += a*b` loop (multiply_sparse.hpp:
+// 219-236): bit-identical values and the same exact-zero drops, at the price of one barrier per
+// A tuple.
+template <int T, int NT, int PB, int MODE>
+__device__ __forceinline__ void hash_products_ordered(const Expand<NT, PB> &X, uint32_t q0, uint32_t q1, const RowMeta &m,
+	int32_t *h_key, double *h_val, uint16_t *occ, uint32_t *s_nocc)
+{
+	const unsigned tid = threadIdx.x;
+	for (uint32_t q = q0; q < q1; ++q) {
+		const uint32_t len = X.cpref[q + 1] - X.cpref[q], start = X.cstart[q];
+		const double a = X.caval[q];
+		for (uint32_t base = 0; base < len; base += NT) {
+			const uint32_t t = base + tid;
+			bool isnew = false;
+			uint32_t h = 0;
+			if (t < len) {
+				const BTup bt = m.btup[start + t];
+				h = hash_slot<T>(bt.col);
+				for (;;) {
+					int32_t old = atomicCAS(&h_key[h], -1, bt.col);
+					if (old == -1) { isnew = true; break; }
+					if (old == bt.col) break;
+					if constexpr ((T & (T - 1)) == 0) h = (h + 1) & (T - 1);
+					else h = h + 1 == (uint32_t)T ? 0u : h + 1;
+				}
+				if (MODE != MODE_COUNT) h_val[h] = h_val[h] + a * btup_val(bt);
+			}
+			uint64_t nm = __ballot(isnew);
+			if (nm) {
+				uint32_t b = 0;
+				if (lane_id() == 0) b = atomicAdd(s_nocc, (uint32_t)__popcll(nm));
+				b = (uint32_t)__shfl((int)b, 0, 64);
+				if (isnew) occ[b + __popcll(nm & lanemask_lt())] = (uint16_t)h;
+			}
+		}
+		lds_barrier();
+	}
+}
+
 struct DigestAcc { unsigned long long cnt, hash; double sum; };
 
 // Emit the occupied slots of the finished cell into the sink and clean them.
@@ -766,7 +809,8 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			if (total == 0) continue;
 			if (!(ep.dbg & 4)) expand_batch(X, 0, total, nzc);
 			if (ep.dbg & 1) total = 0;
-			hash_products<T, NT, T / 2, MODE>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc);
+			if (ep.ordered) hash_products_ordered<T, NT, T / 2, MODE>(X, 0, nzc, m, h_key, h_val, occ, &s_nocc);
+			else hash_products<T, NT, T / 2, MODE>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc);
 			lds_barrier();
 		}
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
@@ -876,7 +920,11 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 		}
 		for (uint32_t c = 0; c < tile.ncells; ++c) {
 			const uint32_t p0 = cellP[c], p1 = cellP[c + 1];
-			hash_products<T, NT, TILE_PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
+			if (ep.ordered) {
+				// the cell's products [p0, p1) are whole segments (a segment belongs to one cell)
+				const uint32_t q0 = expand_lookup(X, p0, 0), q1 = expand_lookup(X, p1 - 1, 0) + 1;
+				hash_products_ordered<T, NT, TILE_PB, MODE>(X, q0, q1, m, h_key, h_val, occ, &s_nocc);
+			} else hash_products<T, NT, TILE_PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
 			lds_barrier();
 			const uint32_t nocc = s_nocc;
 			// the cell's output segment id lives in thread (c, 0): broadcast through LDS
@@ -1176,6 +1224,21 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 			if (total == 0) continue;                               // uniform
 			if (ep.dbg & 8) total = 0;
+			if (ep.ordered && MODE != MODE_COUNT) {
+				// ascending-k accumulation, one segment (unique columns) at a time: see hash_products_ordered
+				lds_barrier();                                      // the compacted segments are visible
+				for (uint32_t q = 0; q < nzc; ++q) {
+					const uint32_t len_q = X.cpref[q + 1] - X.cpref[q], start = X.cstart[q];
+					const double aq = X.caval[q];
+					for (uint32_t t = tid; t < len_q; t += NT) {
+						const BTup bt = m.btup[start + t];
+						const uint32_t slot = (uint32_t)bt.col - wbase;
+						acc[slot] = acc[slot] + aq * btup_val(bt);
+					}
+					lds_barrier();
+				}
+				continue;
+			}
 			// products of the chunk in batches of W
 			for (uint32_t pb = 0; pb < total; pb += W) {
 				const uint32_t pe = min(total, pb + (uint32_t)W);
@@ -1586,7 +1649,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	SPS_LAUNCH_CHECK();
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
-		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0};
+		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0, (a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0};
 
 	// ---- segments (one per light/mid row, one per cell of a heavy row) and the heavy rows' cells
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;

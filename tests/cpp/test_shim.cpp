@@ -184,6 +184,23 @@ static void test_errors_and_append()
 	CHECK(Z.size() == 0);
 }
 
+// multiply_flags = SPSAMD_SINK_ORDERED: a heavy row (> 4096 products) summed in ascending k like
+// multiply_sparse.hpp:219-236 -- ((1e16 + 1) - 1e16) == 0 in that order, so every element is dropped (:238)
+static void test_ordered_flag()
+{
+	const int ncol = 3000;
+	Mat A({1, 3}), B({3, (size_t)ncol}), C;
+	const double bv[3] = {1e16, 1.0, -1e16};
+	for (int k = 0; k < 3; ++k) {
+		A.add({0, k}, 1.0);
+		for (int j = 0; j < ncol; ++j) B.add({k, j}, bv[k]);
+	}
+	multiply_flags = SPSAMD_SINK_ORDERED;
+	multiply(C, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	multiply_flags = 0;
+	CHECK(C.size() == 0 && C.shape[0] == 1 && C.shape[1] == (size_t)ncol);
+}
+
 int main(int argc, char **argv)
 {
 	if (argc > 1 && std::strcmp(argv[1], "--abi-only") == 0) {
@@ -205,6 +222,7 @@ int main(int argc, char **argv)
 	CHECK(nv > 500);
 	test_consolidate();
 	test_errors_and_append();
+	test_ordered_flag();
 	std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
 	return failures ? 1 : 0;
 }

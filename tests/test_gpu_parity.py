@@ -279,6 +279,45 @@ def test_wide_matrix_16k_windows(ctx):
     assert got[3].shape1 == ncol
 
 
+@pytest.mark.parametrize("scale", [11, 14])
+def test_ordered_mode_is_bit_exact(ctx, scale):
+    """SPSAMD_SINK_ORDERED: every sum in ascending k like multiply_sparse.hpp:219-236, so hash,
+    tile and dense-window rows are bit-identical to the oracle too -- on mixed-sign values, where
+    the arrival-order atomics of the default mode would only be within tolerance."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(scale)
+    a = wl.rmat(scale, seed=4)
+    vals = rng.uniform(-1, 1, a[2].size)
+    A = orc.Mat(a[0], a[1], vals, a[3])
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    got = _dev(ctx, A, A, flags=capi.SINK_ORDERED)
+    _check(got, want, exact=True)
+    assert got[3].rows_heavy > 0 and got[3].rows_mid > 0
+    _, _, _, d = _dev(ctx, A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ORDERED)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h
+    # the default mode on the same input: same index set here, values within tolerance of the scale
+    got2 = _dev(ctx, A, A)
+    assert np.array_equal(got2[0], want[0]) and np.array_equal(got2[1], want[1])
+
+
+def test_ordered_mode_exact_cancellation(ctx):
+    """Sums that cancel to exactly 0 only in the reference's summation order are dropped in ordered
+    mode exactly as the reference drops them (multiply_sparse.hpp:238)."""
+    from spsparse_amd import capi
+    # row 0: a_k * b_kj with terms 1e16, 1, -1e16 in ascending k: ((1e16 + 1) - 1e16) == 0 in this order
+    k, ncol = 3, 3000
+    A = orc.Mat([0] * k, list(range(k)), [1.0, 1.0, 1.0], (1, k))
+    bi0 = np.repeat(np.arange(k), ncol)
+    bi1 = np.tile(np.arange(ncol), k)
+    bv = np.repeat(np.array([1e16, 1.0, -1e16]), ncol)
+    B = orc.Mat(bi0, bi1, bv, (k, ncol))
+    want = orc.multiply(A, B, rowwise=True)
+    assert len(want[2]) == 0                                # the reference order cancels every column
+    got = _dev(ctx, A, B, flags=capi.SINK_ORDERED)
+    assert got[3].nnz == 0 and got[3].products == k * ncol
+
+
 def test_poisson_exact(ctx):
     """cfg3 at N=64: values are small integers, so every summation order is exact;
     closed forms nnz(A)=5N^2-4N, P=25N^2-36N+8, nnz(C)=13N^2-20N+4."""
