@@ -10,10 +10,14 @@ line and (N=1) the CPU port of the reference algorithm beside it.
 One step = one pass of the hot path over the whole synthetic matrix:
   N = 1   spsamd_multiply(A, A) from the raw, device-resident COO tuples
           (device consolidate + symbolic + numeric) into the digest sink.
-  N > 1   strong scaling on the same matrix: every rank owns a product-balanced
-          contiguous row block of the raw tuples; a step = consolidate the own
-          block, all-to-allv of the needed B row panels (RCCL), multiply the
-          block against its panel.  C stays row partitioned (no reduction).
+  N > 1   strong scaling on the same matrix: every rank owns a contiguous row
+          block of the raw tuples; a step = consolidate the own block,
+          all-to-allv of the needed B row panels (RCCL), multiply the block
+          against its panel.  C stays row partitioned (no reduction).  The block
+          boundaries are setup: a per-row cost estimate first, then --calibrate
+          rounds of (run the step, gather every rank's local time, move the
+          boundaries so the measured times come out equal); they are fixed
+          before the warmup and timed steps.
 The digest sink (count + value sum + index hash of the emitted tuples) is the
 device analogue of the reference's ScalarAccumulator (accum.hpp:158-167):
 nnz(C) ~ 9.7e9 tuples (155 GB) is never materialised.  Inputs are generated
@@ -41,6 +45,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=14, help="R-MAT scale of the bounded CPU sample")
+    ap.add_argument("--calibrate", type=int, default=2,
+                    help="N>1 setup: measure/rebalance rounds of the row-block boundaries (0: cost estimate only)")
     ap.add_argument("--dist-path", action="store_true",
                     help="with --gpus 1: run the row-block + all-to-allv path on a 1-rank group (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -132,24 +138,59 @@ def main():
         def step():
             return ctx.multiply(A, A, sink=capi.SINK_DIGEST), 0
     else:
-        # setup (untimed): product-balanced contiguous row blocks, identical on every rank
+        # setup (untimed): contiguous row blocks equal in estimated time, identical on every rank ...
         c0, c1, cv = consolidated(capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n)))
         rowlen = torch.bincount(c0.long(), minlength=n)
         P = sd.row_products(c0, c1, rowlen, n)
-        bounds = sd.product_balanced_bounds(sd.row_cost(P), world)     # blocks equal in estimated time
-        del c0, c1, cv, P, rowlen
-        keep = (raw0 >= bounds[rank]) & (raw0 < bounds[rank + 1])
-        blk0, blk1, blkv = raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
-        del raw0, raw1, rawv, keep
-        torch.cuda.empty_cache()
-        nblk = blk0.numel()
+        cost = sd.row_cost(P)
+        cost_prefix = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cost, 0)])
+        bounds = sd.product_balanced_bounds(cost, world)
+        del c0, c1, cv, P, rowlen, cost
 
-        def step():
-            a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), nblk, (n, n)))
-            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds, n)
+        def take_block(b):
+            keep = (raw0 >= b[rank]) & (raw0 < b[rank + 1])
+            return raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
+
+        def run_block(blk):
+            """One step on this rank's block; also returns the time of its local part (consolidate +
+            multiply, without the exchange, where a rank also waits for the slowest one)."""
+            blk0, blk1, blkv = blk
+            t_a = time.perf_counter()
+            a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n)))
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
             Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
             Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
-            return ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST), remote
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            res = ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST)
+            t_d = time.perf_counter()
+            return res, remote, ((t_b - t_a) + (t_d - t_c)) * 1e3
+
+        # ... then corrected by measurement: run the step, gather every rank's local time, move the
+        # boundaries so that the measured times come out equal (sd.rebalance_bounds), repeat.
+        bounds_now = [bounds]
+        calib = []
+        for _ in range(max(0, args.calibrate) if world > 1 or args.dist_path else 0):
+            blk = take_block(bounds_now[0])
+            run_block(blk)
+            _, _, local_ms = run_block(blk)
+            mine = torch.tensor([local_ms], dtype=torch.float64, device=dev)
+            every = torch.empty(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine)
+            times = [float(x) for x in every.tolist()]
+            calib.append([round(x, 2) for x in times])
+            bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times)
+            del blk
+        bounds = bounds_now[0]
+        block = take_block(bounds)
+        del raw0, raw1, rawv, cost_prefix
+        torch.cuda.empty_cache()
+
+        def step():
+            res, remote, _ = run_block(block)
+            return res, remote
 
     def barrier():
         if use_dist:
@@ -224,8 +265,9 @@ def main():
                 "workload": "R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
                             "raw COO tuples resident in HBM, digest sink" % (scale, seed),
                 "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
-                "parallelism": "1 GPU" if world == 1 else "%d row blocks (balanced by per-row cost estimate) + all-to-allv of B row panels" % world,
+                "parallelism": "1 GPU" if world == 1 else "%d row blocks (per-row cost estimate, then %d measure/rebalance rounds) + all-to-allv of B row panels" % (world, len(calib)),
                 "remote_panel_tuples": remote_total,
+                "calibration_local_ms": calib if use_dist else None,
                 "digest": {"sum": vsum, "hash": "%016x" % vhash},
                 "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,
                 "products_per_s": products / (ms_step * 1e-3),

@@ -35,21 +35,25 @@ def main():
     for _ in range(2):
         full = ctx.multiply(B, B, sink=capi.SINK_DIGEST)
     print("full: %.1f ms" % full.ms_total)
+    cost = sd.row_cost(P) if mode == "cost" else P
+    cost_prefix = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cost, 0)])
     for world in (2, 4, 8):
-        bounds = sd.product_balanced_bounds(sd.row_cost(P) if mode == "cost" else P, world)
-        times, prods = [], []
-        for rank in range(world):
-            keep = (c0 >= bounds[rank]) & (c0 < bounds[rank + 1])
-            a0, a1, av = c0[keep].contiguous(), c1[keep].contiguous(), cv[keep].contiguous()
-            A = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
-            res = None
-            for _ in range(2):
-                res = ctx.multiply(A, B, sink=capi.SINK_DIGEST)
-            times.append(res.ms_total)
-            prods.append(res.products)
-        print("world %d (%s): block ms %s | max %.1f -> speed-up %.2fx (compute only) | products %s" % (
-            world, mode, " ".join("%.1f" % t for t in times), max(times), full.ms_total / max(times),
-            " ".join("%.2g" % p for p in prods)))
+        bounds = sd.product_balanced_bounds(cost, world)
+        for rnd in range(4):                      # round 0: the estimate alone; then measure -> rebalance
+            times, prods = [], []
+            for rank in range(world):
+                keep = (c0 >= bounds[rank]) & (c0 < bounds[rank + 1])
+                a0, a1, av = c0[keep].contiguous(), c1[keep].contiguous(), cv[keep].contiguous()
+                A = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
+                res = None
+                for _ in range(2):
+                    res = ctx.multiply(A, B, sink=capi.SINK_DIGEST)
+                times.append(res.ms_total)
+                prods.append(res.products)
+            print("world %d (%s) round %d: block ms %s | max %.1f -> speed-up %.2fx (compute only) | products %s" % (
+                world, mode, rnd, " ".join("%.1f" % t for t in times), max(times), full.ms_total / max(times),
+                " ".join("%.2g" % p for p in prods)), flush=True)
+            bounds = sd.rebalance_bounds(bounds, cost_prefix, times)
 
 
 def fixed_cost():

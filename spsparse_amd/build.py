@@ -21,6 +21,7 @@ HEADERS = ["internal.h", "devutil.h", "workload_common.h", os.path.join("..", ".
 # -munsafe-fp-atomics: f64 atomic adds compile to ds_add_f64 / global_atomic_add_f64.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result"]
+FLAGS += os.environ.get("SPSAMD_CXXFLAGS", "").split()      # developer experiments (-DDENSE_U=4 ...)
 
 
 def hipcc():

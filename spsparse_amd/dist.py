@@ -49,6 +49,43 @@ def row_cost(row_products_):
     return (P * w).round().to(torch.int64)
 
 
+def rebalance_bounds(bounds, cost_prefix, block_ms, fixed_ms=0.0):
+    """New contiguous row-block boundaries from MEASURED per-block times.
+
+    bounds       current boundaries [0, b1, ..., n]
+    cost_prefix  exclusive prefix sum of the per-row cost estimate, [n+1] (cost_prefix[n] = total)
+    block_ms     measured local time of every block under `bounds` (same list on every rank)
+    fixed_ms     part of every block's time that does not move with its rows
+
+    Inside a block the measured time (less fixed_ms) is spread over its rows in proportion to the
+    cost estimate, which gives a piecewise-linear cumulative time over the rows; the new
+    boundaries cut it into equal parts.  One or two rounds (measure, rebalance) make the blocks
+    equal in time even where the estimate is off by a block-dependent factor."""
+    nparts = len(bounds) - 1
+    n = bounds[-1]
+    cp = cost_prefix.to(torch.float64)
+    var = [max(float(t) - fixed_ms, 1e-9) for t in block_ms]
+    total = sum(var)
+    cum = [0.0]
+    for v in var:
+        cum.append(cum[-1] + v)
+    new = [0]
+    q = 0
+    for j in range(1, nparts):
+        target = total * j / nparts
+        while q + 1 < nparts and cum[q + 1] <= target:
+            q += 1
+        lo, hi = bounds[q], bounds[q + 1]
+        c_lo, c_hi = float(cp[lo]), float(cp[hi])
+        frac = (target - cum[q]) / var[q]
+        want = c_lo + frac * (c_hi - c_lo)
+        # first row boundary whose cost prefix reaches `want`, inside the block
+        r = int(torch.searchsorted(cp[lo:hi + 1].contiguous(), torch.tensor([want], dtype=torch.float64, device=cp.device))[0]) + lo
+        new.append(min(max(r, new[-1]), n))
+    new.append(n)
+    return new
+
+
 def row_products(a_row, a_col, b_rowlen, n_rows):
     """P_r = sum over tuples (r,k) of A of the length of B row k. int64 [n_rows]."""
     out = torch.zeros(n_rows, dtype=torch.int64, device=a_row.device)

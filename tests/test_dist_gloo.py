@@ -112,6 +112,34 @@ def test_row_cost_weights():
     assert b[0] == 0 and b[-1] == 8 and 0 < b[1] <= 8
 
 
+def test_rebalance_from_measured_times():
+    """Blocks whose true cost deviates from the estimate by a block-dependent factor (plus a fixed
+    part) become equal in time after a few measure/rebalance rounds."""
+    g = torch.Generator().manual_seed(5)
+    n, world = 20000, 8
+    est = torch.randint(1, 1000, (n,), generator=g, dtype=torch.int64)
+    est[:50] *= 100                                            # a few hub rows, like an un-permuted R-MAT
+    skew = 0.5 + 4.0 * torch.linspace(1, 0, n, dtype=torch.float64) ** 2      # true cost per estimated unit varies along the rows
+    true = est.to(torch.float64) * skew
+    tp = torch.cat([torch.zeros(1, dtype=torch.float64), torch.cumsum(true, 0)])
+    cp = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(est, 0)])
+    fixed = 0.02 * float(tp[-1]) / world
+
+    def measure(b):
+        return [fixed + float(tp[b[q + 1]] - tp[b[q]]) for q in range(world)]
+    b = sd.product_balanced_bounds(est, world)
+    t0 = measure(b)
+    assert max(t0) / (sum(t0) / world) > 1.2                    # the estimate alone is badly off
+    for _ in range(3):
+        b = sd.rebalance_bounds(b, cp, measure(b), fixed_ms=0.0)
+        assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:]))
+    t2 = measure(b)
+    assert max(t2) / (sum(t2) / world) < 1.06
+    # equal measured times leave the boundaries where they are (up to one row)
+    b2 = sd.rebalance_bounds(b, cp, [1.0] * world)
+    assert all(abs(x - y) <= 1 for x, y in zip(b2, b))
+
+
 def test_balanced_bounds_edge_cases():
     P = torch.tensor([0, 0, 10, 0, 5, 5, 0], dtype=torch.int64)
     b = sd.product_balanced_bounds(P, 2)
