@@ -91,6 +91,9 @@ typedef struct {
 
 /* sink flags */
 #define SPSAMD_SINK_ROWSTATS  1   /* DIGEST: also fill row_nnz / row_sum (length = rows of op(A)) */
+#define SPSAMD_SINK_PERMUTE   4   /* COO, matrix result: emit (j, i, v) -- idx0 holds the column, idx1 the row, shape
+                                   * swapped (PermuteAccum with perm {1,0}, accum.hpp:73-101; the tuples stay in
+                                   * the order of C's rows, i.e. column-major for the permuted array) */
 #define SPSAMD_SINK_ORDERED   2   /* every sum accumulated in ascending k like the reference's loop
                                    * (multiply_sparse.hpp:219-236): bit-identical values and zero drops on
                                    * any input, several times slower on rows with more than 64 products */

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <array>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -143,6 +144,14 @@ public:
 		val_vec.push_back(val);
 	}
 
+	// VectorCooArray.hpp:143-147: the index columns are permuted in place; like the reference's
+	// OverwriteAccum it leaves shape and sort_order as they were.
+	void transpose(std::array<int, RANK> const &perm)
+	{
+		std::array<std::vector<IndexT>, RANK> old(index_vecs);
+		for (int new_k = 0; new_k < RANK; ++new_k) index_vecs[new_k] = old[perm[new_k]];
+	}
+
 	// In-place device consolidate (VectorCooArray.hpp:299-311), rank 2 only.
 	void consolidate(std::array<int, RANK> const &_sort_order, DuplicatePolicy duplicate_policy = DuplicatePolicy::ADD,
 		bool handle_nan = false);
@@ -151,6 +160,75 @@ protected:
 	std::array<std::vector<IndexT>, RANK> index_vecs;
 	std::vector<ValT> val_vec;
 };
+
+// ---- the accumulators of accum.hpp that make sense around multiply(), host side -------------
+// (the device analogues are sink flags / entry points of the C ABI: SPSAMD_SINK_PERMUTE,
+//  spsamd_result_scatter_dense, SPSAMD_SINK_DIGEST)
+
+// accum.hpp:73-101.  Unlike the reference's it forwards set_shape (permuted), so it can be the sink of multiply().
+template <int IN_RANK, class AccumulatorT>
+class PermuteAccum {
+	AccumulatorT &sub;
+	std::vector<int> perm;
+public:
+	static const int rank = IN_RANK;
+	typedef typename AccumulatorT::val_type val_type;
+	PermuteAccum(AccumulatorT &_sub, std::vector<int> const &_perm) : sub(_sub), perm(_perm) {}
+	void set_shape(std::array<size_t, IN_RANK> const &shape)
+	{
+		std::array<size_t, AccumulatorT::rank> out;
+		for (int i = 0; i < AccumulatorT::rank; ++i) out[i] = shape[perm[i]];
+		sub.set_shape(out);
+	}
+	void add(std::array<int, IN_RANK> const &index, val_type const &val)
+	{
+		std::array<int, AccumulatorT::rank> out;
+		for (int i = 0; i < AccumulatorT::rank; ++i) out[i] = index[perm[i]];
+		sub.add(out, val);
+	}
+};
+
+// accum.hpp:110-140 on a caller-owned row-major dense matrix (the reference writes a blitz::Array).
+template <class IndexT, class ValT>
+struct DenseAccum {
+	static const int rank = 2;
+	typedef ValT val_type;
+	ValT *dense; size_t ld;
+	DuplicatePolicy duplicate_policy;
+	DenseAccum(ValT *_dense, size_t _ld, DuplicatePolicy _p = DuplicatePolicy::ADD) : dense(_dense), ld(_ld), duplicate_policy(_p) {}
+	void set_shape(std::array<size_t, 2> const &) {}
+	void add(std::array<IndexT, 2> const &index, ValT const &val)
+	{
+		ValT &oval = dense[(size_t)index[0] * ld + (size_t)index[1]];
+		switch (duplicate_policy) {
+			case DuplicatePolicy::LEAVE_ALONE: if (!std::isnan(oval)) oval = val; break;     // accum.hpp:128-130, as written there
+			case DuplicatePolicy::ADD: oval += val; break;
+			case DuplicatePolicy::REPLACE: oval = val; break;
+		}
+	}
+};
+
+// accum.hpp:158-167
+template <class IndexT, class ValT, int RANK>
+struct ScalarAccumulator {
+	static const int rank = RANK;
+	typedef ValT val_type;
+	ValT val;
+	ScalarAccumulator() : val(0) {}
+	void set_shape(std::array<size_t, RANK> const &) {}
+	void add(std::array<IndexT, RANK> const &, ValT const &v) { val += v; }
+};
+
+// algorithm.hpp:46-57: ret.dim[i] == A.dim[perm[i]]
+template <class VectorCooArrayT, class AccumulatorT>
+void transpose(AccumulatorT &ret, VectorCooArrayT const &A, std::array<int, VectorCooArrayT::rank> const &perm)
+{
+	std::array<typename VectorCooArrayT::index_type, VectorCooArrayT::rank> idx;
+	for (size_t i = 0; i < A.size(); ++i) {
+		for (int new_k = 0; new_k < VectorCooArrayT::rank; ++new_k) idx[new_k] = A.index(perm[new_k], i);
+		ret.add(idx, A.val(i));
+	}
+}
 
 template <class IndexT, class ValT>
 using VectorCooMatrix = VectorCooArray<IndexT, ValT, 2>;

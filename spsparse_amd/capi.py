@@ -18,6 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SINK_COO, SINK_DIGEST = 1, 2
 SINK_ROWSTATS = 1
 SINK_ORDERED = 2
+SINK_PERMUTE = 4
 
 ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE"}
 

@@ -97,8 +97,9 @@ static int multiply_body(spsamd_ctx *c, double C,
 	const int a0 = transpose_A == 'T' ? 1 : 0, a1 = 1 - a0;
 	const int bk = transpose_B == 'T' ? 1 : 0, bj = 1 - bk;
 	const size_t ashape[2] = {A->shape0, A->shape1}, bshape[2] = {B->shape0, B->shape1};
-	res->shape0 = ashape[a0];
-	res->shape1 = bshape[bj];
+	const bool permute = (sink_flags & SPSAMD_SINK_PERMUTE) && sink_kind == SPSAMD_SINK_COO;
+	res->shape0 = permute ? bshape[bj] : ashape[a0];
+	res->shape1 = permute ? ashape[a0] : bshape[bj];
 	if (ashape[a1] != bshape[bk]) {                                  // :172-174
 		char buf[160];
 		std::snprintf(buf, sizeof buf, "Inner dimensions for A (%ld) and %s (%ld) must match!", (long)ashape[a1], what, (long)bshape[bk]);
@@ -121,6 +122,7 @@ static int multiply_body(spsamd_ctx *c, double C,
 	upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
 	upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
 	spgemm(c, a, res);
+	if (permute) std::swap(res->idx0, res->idx1);                             // PermuteAccum {1,0}: same tuples, indices swapped
 	SPS_HIP(hipEventRecord(c->ev[7], st));
 	SPS_HIP(hipEventSynchronize(c->ev[7]));
 	if (res->nnz_a && res->nnz_b) {
@@ -174,7 +176,7 @@ extern "C" int spsamd_multiply_mv(spsamd_ctx *c, double C,
 			Vm.idx0 = vi; Vm.idx1 = vz; Vm.val = vv;
 		}
 		int rc = multiply_body(c, C, scalei, A, transpose_A, scalej, &Vm, '.', nullptr, duplicate_policy, zero_nan,
-			sink_kind, sink_flags, res, "V", true);
+			sink_kind, sink_flags & ~SPSAMD_SINK_PERMUTE, res, "V", true);     // a rank-1 result has nothing to permute
 		res->shape1 = 0;                              // rank-1 result: ret.set_shape({rows}) (:295)
 		return rc;
 	)

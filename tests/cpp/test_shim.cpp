@@ -138,6 +138,49 @@ static void test_consolidate()
 	for (size_t q = 0; q < arr4.size() && q < 4; ++q) CHECK(arr4.index(0, q) == f0[q] && arr4.index(1, q) == f1[q] && arr4.val(q) == fv[q]);
 }
 
+// tests/test_array.cpp:108-131
+static void test_transpose()
+{
+	Mat arr2({2, 4});
+	arr2.add({1, 3}, 5.); arr2.add({1, 2}, 3.); arr2.add({0, 3}, 17.); arr2.add({0, 1}, 14.); arr2.add({1, 2}, 15.);
+	const int i0[] = {1, 1, 0, 0, 1}, j0[] = {3, 2, 3, 1, 2}; const double v0[] = {5., 3., 17., 14., 15.};
+	arr2.transpose({0, 1});
+	for (size_t q = 0; q < 5; ++q) CHECK(arr2.index(0, q) == i0[q] && arr2.index(1, q) == j0[q] && arr2.val(q) == v0[q]);
+	arr2.transpose({1, 0});
+	for (size_t q = 0; q < 5; ++q) CHECK(arr2.index(0, q) == j0[q] && arr2.index(1, q) == i0[q] && arr2.val(q) == v0[q]);
+	arr2.transpose({1, 0});
+	for (size_t q = 0; q < 5; ++q) CHECK(arr2.index(0, q) == i0[q] && arr2.index(1, q) == j0[q] && arr2.val(q) == v0[q]);
+	// the free function into a fresh array (algorithm.hpp:46-57)
+	Mat t({4, 2});
+	transpose(t, arr2, {1, 0});
+	CHECK(t.size() == 5);
+	for (size_t q = 0; q < t.size() && q < 5; ++q) CHECK(t.index(0, q) == j0[q] && t.index(1, q) == i0[q] && t.val(q) == v0[q]);
+}
+
+// multiply() into the accumulators of accum.hpp (PermuteAccum with the set_shape it lacks upstream, DenseAccum, ScalarAccumulator)
+static void test_accumulator_sinks()
+{
+	Mat A({3, 4}), B({4, 2}), C;
+	A.add({0, 1}, 2.); A.add({2, 3}, -1.); A.add({0, 0}, 1.); A.add({1, 2}, 4.);
+	B.add({1, 0}, 3.); B.add({3, 1}, 5.); B.add({0, 0}, 7.); B.add({2, 1}, .5); B.add({1, 1}, 1.);
+	multiply(C, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	CHECK(C.size() == 4);                               // (0,0)=13 (0,1)=2 (1,1)=2 (2,1)=-5
+	Mat Ct;
+	PermuteAccum<2, Mat> perm(Ct, {1, 0});
+	multiply(perm, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	CHECK(Ct.shape[0] == 2 && Ct.shape[1] == 3 && Ct.size() == C.size());
+	for (size_t q = 0; q < C.size() && q < Ct.size(); ++q)
+		CHECK(Ct.index(0, q) == C.index(1, q) && Ct.index(1, q) == C.index(0, q) && Ct.val(q) == C.val(q));
+	double dense[6] = {100, 0, 0, 0, 0, 0};
+	DenseAccum<int, double> dacc(dense, 2);
+	multiply(dacc, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	const double want[6] = {113, 2, 0, 2, 0, -5};
+	for (int q = 0; q < 6; ++q) CHECK(dense[q] == want[q]);
+	ScalarAccumulator<int, double, 2> sacc;
+	multiply(sacc, 2.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	CHECK(sacc.val == 2.0 * (13 + 2 + 2 - 5));
+}
+
 static int handler_calls = 0;
 static char handler_msg[256];
 static void recording_handler(int, const char *fmt, ...)
@@ -221,6 +264,8 @@ int main(int argc, char **argv)
 	std::printf("random_MV_multiply: 999 seeds, %ld tuples\n", nv);
 	CHECK(nv > 500);
 	test_consolidate();
+	test_transpose();
+	test_accumulator_sinks();
 	test_errors_and_append();
 	test_ordered_flag();
 	std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);

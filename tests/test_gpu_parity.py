@@ -487,6 +487,31 @@ def test_dense_accumulator_sink(ctx):
         ctx.scatter_dense(res, dense.data_ptr(), 40)
 
 
+def test_permute_sink_flag(ctx):
+    """PermuteAccum {1,0} analogue (accum.hpp:73-101): SPSAMD_SINK_PERMUTE emits (j, i, v) with the shape
+    swapped; scattered into a dense matrix it is the transpose of the plain result.  MV ignores the flag."""
+    import torch
+    from spsparse_amd import capi
+    rng = np.random.default_rng(9)
+    A, B = _rand_mat(rng, (37, 50), 400), _rand_mat(rng, (50, 41), 500)
+    wi, wj, wv, _ = orc.multiply(A, B)
+    i, j, v, res = _dev(ctx, A, B, flags=capi.SINK_PERMUTE)
+    assert (res.shape0, res.shape1) == (41, 37)
+    assert np.array_equal(i, wj) and np.array_equal(j, wi)
+    assert np.allclose(v, wv, rtol=1e-12, atol=0)
+    dense = torch.zeros((41, 37), dtype=torch.float64, device="cuda:0")
+    ctx.scatter_dense(res, dense.data_ptr(), 37, capi.ADD)
+    want = np.zeros((37, 41))
+    want[wi, wj] = wv
+    assert np.allclose(dense.cpu().numpy(), want.T, rtol=1e-12, atol=0)
+    # shape is set (permuted) before the dimension check, as the sink's set_shape would be (:169)
+    bad = _rand_mat(rng, (49, 41), 10)
+    a, ka = capi.host_coo(A.idx0, A.idx1, A.val, A.shape)
+    b, kb = capi.host_coo(bad.idx0, bad.idx1, bad.val, bad.shape)
+    with pytest.raises(capi.SpsamdError, match="Inner dimensions"):
+        ctx.multiply(a, b, flags=capi.SINK_PERMUTE)
+
+
 def test_device_generators_match_numpy(ctx):
     """csrc/workload.hip == spsparse_amd/workloads.py, tuple for tuple."""
     import torch
