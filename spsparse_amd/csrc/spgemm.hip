@@ -46,6 +46,8 @@ struct EmitParams {
 	const int32_t *si_pos; const double *si_val;     // row scale (null: none)
 	const int32_t *sk_pos; const double *sk_val;     // column scale (null: none)
 	int dbg;                                         // developer ablation switches (0 in production)
+	uint32_t wshift;                                 // log2 of the column-window width of the heavy path (0 before it is chosen)
+	uint32_t ncolbits;                               // bits of the largest column index
 	int ordered;                                     // SPSAMD_SINK_ORDERED: ascending-k sums everywhere (bit-exact)
 };
 
@@ -651,12 +653,74 @@ __device__ __forceinline__ void hash_products_ordered(const Expand<NT, PB> &X, u
 	}
 }
 
+// Stable LSD radix sort (4-bit digits) of n packed 32-bit keys in LDS on the bits
+// [lowbit, lowbit + nbits).  a holds the keys, b is scratch of the same size; returns the array
+// that holds the sorted keys.  Element i = r*NT + tid belongs to (round r, wave, lane); a key's
+// position is (keys with a smaller digit) + (same digit in an earlier round / wave) + (same digit
+// in a lower lane): one 16-bit counter per (digit, round, wave), filled by wave ballots, scanned
+// once per pass.  Replaces a bitonic network of 66 barrier-separated stages for 2048 keys.
+template <int NT, int EMAX>
+__device__ __forceinline__ uint32_t *lds_radix_sort(uint32_t *a, uint32_t *b, uint32_t n, uint32_t lowbit, uint32_t nbits,
+	uint16_t *cnt, uint32_t *scr32)
+{
+	constexpr int NW = NT / 64;
+	constexpr int NC = 16 * EMAX * NW;
+	constexpr int PER = (NC + NT - 1) / NT;
+	const unsigned tid = threadIdx.x, wv = wave_id();
+	const uint32_t rounds = (n + NT - 1) / NT;
+	if (n <= 1) return a;                                               // uniform
+	for (uint32_t shift = lowbit; shift < lowbit + nbits; shift += 4) {
+		for (int q = tid; q < NC; q += NT) cnt[q] = 0;
+		__syncthreads();
+		uint32_t key[EMAX], where[EMAX];
+#pragma unroll
+		for (int r = 0; r < EMAX; ++r) {
+			key[r] = 0; where[r] = 0xFFFFFFFFu;
+			if ((uint32_t)r < rounds) {                                    // uniform
+				const uint32_t i = r * NT + tid;
+				const bool ok = i < n;
+				const uint32_t k = ok ? a[i] : 0u;
+				const uint32_t d = (k >> shift) & 15u;
+				uint64_t m = __ballot(ok);
+#pragma unroll
+				for (int bit = 0; bit < 4; ++bit) {
+					const bool set = (d >> bit) & 1u;
+					const uint64_t bm = __ballot(set);
+					m &= set ? bm : ~bm;
+				}
+				const uint32_t before = (uint32_t)__popcll(m & lanemask_lt());
+				const uint32_t slot = (d * EMAX + r) * NW + wv;
+				if (ok && before == 0) cnt[slot] = (uint16_t)__popcll(m);
+				key[r] = k;
+				if (ok) where[r] = (slot << 8) | before;                   // before < 64
+			}
+		}
+		__syncthreads();
+		{
+			uint32_t loc[PER], sum = 0;
+#pragma unroll
+			for (int q = 0; q < PER; ++q) { const int e = tid * PER + q; loc[q] = e < NC ? cnt[e] : 0u; sum += loc[q]; }
+			uint32_t ex = block_exclusive_scan<uint32_t, NT>(sum, scr32, (uint32_t *)nullptr);
+#pragma unroll
+			for (int q = 0; q < PER; ++q) { const int e = tid * PER + q; if (e < NC) cnt[e] = (uint16_t)ex; ex += loc[q]; }
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < EMAX; ++r)
+			if (where[r] != 0xFFFFFFFFu) b[cnt[where[r] >> 8] + (where[r] & 63u)] = key[r];
+		__syncthreads();
+		uint32_t *t = a; a = b; b = t;
+	}
+	return a;
+}
+
 struct DigestAcc { unsigned long long cnt, hash; double sum; };
 
 // Emit the occupied slots of the finished cell into the sink and clean them.
 template <int T, int NT, int MODE>
 __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t seg, const EmitParams &ep, const SinkParams &sk,
-	int32_t *h_key, double *h_val, const uint16_t *occ, uint64_t *s_sort, uint32_t *scr32, DigestAcc &d)
+	int32_t *h_key, double *h_val, const uint16_t *occ, uint64_t *s_sort, uint32_t *scr32, DigestAcc &d,
+	uint16_t *s_cnt, uint32_t colbase, uint32_t colbits)
 {
 	const unsigned tid = threadIdx.x;
 	const double a_scale = row_scale(ep, rowid);
@@ -682,6 +746,97 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
 		}
 	} else {
+		// surviving columns -> sorted -> emitted in order, cleaning the table.  Where the cell's column
+		// range and the position in the occupied list fit one 32-bit word (they do for every cell of a
+		// matrix with up to 2^20 columns) the keys are radix sorted, otherwise by the bitonic network.
+		constexpr uint32_t PBITS = T <= 1024 ? 9 : (T <= 4096 ? 11 : 12);          // position in occ[] (< T/2)
+		constexpr int EMAX = (T / 2 + NT - 1) / NT;
+		// Narrow cells (column range <= 32*T bits, e.g. 16 windows of 8192 for T = 4096): no sort at all.
+		// The surviving columns set bits in a bitmap laid over s_sort; the rank of a column is the number
+		// of bits below it = prefix count of its 4-word superblock (s_cnt) + popcounts of at most three
+		// words + its own word below the bit, and the tuple is stored straight at segoff + rank.
+		const uint32_t colrange = colbits >= 32 ? 0xFFFFFFFFu : (1u << colbits);
+		constexpr int NSB = T / 8;                                         // superblocks of 4 words, one per thread in the scan
+		if (NSB <= NT && colrange <= (uint32_t)T * 32u && !(ep.dbg & 1024)) {
+			static_assert(NSB <= 16 * EMAX * (NT / 64), "s_cnt holds the superblock prefixes");
+			unsigned long long *bm = (unsigned long long *)s_sort;
+			const uint32_t nwords = (colrange + 63u) >> 6, nsb = (nwords + 3u) >> 2;
+			for (uint32_t w = tid; w < nsb * 4u; w += NT) bm[w] = 0ull;
+			lds_barrier();
+			uint32_t rel[EMAX], slot[EMAX];
+#pragma unroll
+			for (int r = 0; r < EMAX; ++r) {
+				rel[r] = 0xFFFFFFFFu; slot[r] = 0;
+				const uint32_t i = r * NT + tid;
+				if (i < nocc) {
+					const uint32_t h = occ[i];
+					const int32_t col = h_key[h];
+					double v = 0;
+					const bool ok = emit_value(ep, a_scale, col, h_val[h], &v);
+					h_key[h] = -1;
+					h_val[h] = ok ? v : 0.0;
+					if (ok) {
+						rel[r] = (uint32_t)col - colbase; slot[r] = h;
+						atomicOr(&bm[rel[r] >> 6], 1ull << (rel[r] & 63u));
+					}
+				}
+			}
+			lds_barrier();
+			uint32_t c4 = 0;
+			if (tid < nsb) c4 = (uint32_t)(__popcll(bm[4 * tid]) + __popcll(bm[4 * tid + 1]) + __popcll(bm[4 * tid + 2]) + __popcll(bm[4 * tid + 3]));
+			uint32_t mcount = 0, ex = 0;
+			ex = block_exclusive_scan<uint32_t, NT>(c4, scr32, &mcount);
+			if (tid < nsb) s_cnt[tid] = (uint16_t)ex;
+			lds_barrier();
+			const int64_t o = sk.segoff[seg];
+#pragma unroll
+			for (int r = 0; r < EMAX; ++r) {
+				if (rel[r] != 0xFFFFFFFFu) {
+					const uint32_t w = rel[r] >> 6, sb = w >> 2;
+					uint32_t rank = s_cnt[sb] + (uint32_t)__popcll(bm[w] & ((1ull << (rel[r] & 63u)) - 1ull));
+					for (uint32_t q = sb * 4u; q < w; ++q) rank += (uint32_t)__popcll(bm[q]);
+					sk.out_i[o + rank] = rowid;
+					sk.out_j[o + rank] = (int32_t)(colbase + rel[r]);
+					sk.out_v[o + rank] = h_val[slot[r]];
+					h_val[slot[r]] = 0.0;
+				}
+			}
+			if (tid == 0) sk.segactual[seg] = mcount;
+			return;
+		}
+		if (colbits + PBITS <= 32 && !(ep.dbg & 512)) {
+			uint32_t *ka = (uint32_t *)s_sort, *kb = ka + T / 2;
+			uint32_t run = 0;
+			for (uint32_t base = 0; base < nocc; base += NT) {
+				uint32_t i = base + tid;
+				bool ok = false;
+				int32_t col = 0;
+				if (i < nocc) {
+					uint32_t h = occ[i]; col = h_key[h];
+					double v = 0;
+					ok = emit_value(ep, a_scale, col, h_val[h], &v);
+					h_key[h] = -1;
+					h_val[h] = ok ? v : 0.0;
+				}
+				uint32_t total;
+				uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, scr32, &total);
+				if (ok) ka[run + ex] = (((uint32_t)col - colbase) << PBITS) | i;
+				run += total;
+			}
+			const uint32_t mcount = run;
+			uint32_t *srt = lds_radix_sort<NT, EMAX>(ka, kb, mcount, PBITS, colbits, s_cnt, scr32);
+			int64_t o = sk.segoff[seg];
+			for (uint32_t i = tid; i < mcount; i += NT) {
+				uint32_t kq = srt[i];
+				uint32_t h = occ[kq & ((1u << PBITS) - 1u)];
+				sk.out_i[o + i] = rowid;
+				sk.out_j[o + i] = (int32_t)(colbase + (kq >> PBITS));
+				sk.out_v[o + i] = h_val[h];
+				h_val[h] = 0.0;
+			}
+			if (tid == 0) sk.segactual[seg] = mcount;
+			return;
+		}
 		// surviving (col, slot) pairs -> bitonic sort by column -> emit in order, cleaning the table
 		uint32_t run = 0;
 		for (uint32_t base = 0; base < nocc; base += NT) {
@@ -705,7 +860,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		while (n2 < mcount) n2 <<= 1;
 		for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
 		__syncthreads();
-		for (uint32_t k = 2; k <= n2; k <<= 1) {
+		for (uint32_t k = 2; k <= n2 && !(ep.dbg & 256); k <<= 1) {
 			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
 				for (uint32_t i = tid; i < n2; i += NT) {
 					uint32_t ixj = i ^ j;
@@ -741,6 +896,7 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
 	__shared__ uint16_t occ[T / 2];
 	__shared__ uint64_t s_sort[MODE == MODE_STORE ? T / 2 : 1];
+	__shared__ uint16_t s_cnt[MODE == MODE_STORE ? 16 * ((T / 2 + NT - 1) / NT) * (NT / 64) : 1];
 	__shared__ Expand<NT, T / 2> X;
 	__shared__ uint32_t scr32[NT / 64 + 1];
 	__shared__ uint32_t s_nocc;
@@ -823,7 +979,9 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		lds_barrier();
 		uint32_t nocc = s_nocc;
 		if (ep.dbg & 2) nocc = 0;
-		hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc);
+		uint32_t colbase = 0, colbits = ep.ncolbits;
+		if (WINDOWED) { colbase = wa << ep.wshift; colbits = ep.wshift + (wb - wa > 1 ? 32 - __builtin_clz(wb - wa - 1) : 0); }
+		hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
 	}
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
 }
@@ -835,7 +993,8 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 // the tile; the cells are then accumulated one after the other in the same LDS table.
 constexpr int TILE_NT = 512;
 constexpr int TILE_T = 4096;
-constexpr int TILE_PB = 16384;
+constexpr int TILE_PB = 16384;          // products per tile, DIGEST / COUNT launches
+constexpr int TILE_PB_STORE = 12288;    // ... when the tiles also serve a STORE launch: its LDS then allows two workgroups per CU
 constexpr uint32_t TILE_LMAX = 256;
 constexpr uint32_t TILE_MAXCELLS = 16;
 
@@ -851,7 +1010,9 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
 	__shared__ uint16_t occ[T / 2];
 	__shared__ uint64_t s_sort[MODE == MODE_STORE ? T / 2 : 1];
-	__shared__ Expand<NT, TILE_PB> X;
+	__shared__ uint16_t s_cnt[MODE == MODE_STORE ? 16 * ((T / 2 + NT - 1) / NT) * (NT / 64) : 1];
+	constexpr int PB = MODE == MODE_STORE ? TILE_PB_STORE : TILE_PB;
+	__shared__ Expand<NT, PB> X;
 	__shared__ uint32_t scr32[NT / 64 + 1];
 	__shared__ uint32_t s_nocc;
 	__shared__ uint32_t cellP[TILE_MAXCELLS + 1];
@@ -923,8 +1084,8 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 			if (ep.ordered) {
 				// the cell's products [p0, p1) are whole segments (a segment belongs to one cell)
 				const uint32_t q0 = expand_lookup(X, p0, 0), q1 = expand_lookup(X, p1 - 1, 0) + 1;
-				hash_products_ordered<T, NT, TILE_PB, MODE>(X, q0, q1, m, h_key, h_val, occ, &s_nocc);
-			} else hash_products<T, NT, TILE_PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
+				hash_products_ordered<T, NT, PB, MODE>(X, q0, q1, m, h_key, h_val, occ, &s_nocc);
+			} else hash_products<T, NT, PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
 			lds_barrier();
 			const uint32_t nocc = s_nocc;
 			// the cell's output segment id lives in thread (c, 0): broadcast through LDS
@@ -932,7 +1093,13 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 			lds_barrier();
 			const uint32_t seg = scr32[NT / 64];
 			if (tid == 0) s_nocc = 0;
-			hash_emit<T, NT, MODE>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc);
+			uint32_t colbase = 0, colbits = 0;
+			if (MODE == MODE_STORE) {
+				const TCell tcc = tcells[tile.first + c];                  // uniform
+				colbase = (uint32_t)tcc.wa << ep.wshift;
+				colbits = ep.wshift + (tcc.wb - tcc.wa > 1 ? 32 - __builtin_clz((uint32_t)(tcc.wb - tcc.wa) - 1u) : 0);
+			}
+			hash_emit<T, NT, MODE>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
 			lds_barrier();
 		}
 	}
@@ -1035,7 +1202,7 @@ struct CellLists { Cell *list[NCLS]; };
 
 // Greedy grouping of a heavy row's windows into cells.  WRITE = false counts
 // the cells per class (and the row's segment count); WRITE = true emits them.
-struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; };
+struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; };
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
@@ -1073,7 +1240,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	auto flush = [&]() {
 		if (!cur) return;
 		if (tileable && cur <= (uint32_t)(TILE_T / 2)) {
-			if (tcnt == G || tprods + cur > (uint32_t)TILE_PB) close_tile();
+			if (tcnt == G || tprods + cur > tb.pb) close_tile();
 			if (!tcnt) { tfirst = ntc; twa0 = start; }
 			if (WRITE) {
 				TCell tc; tc.wa = (uint16_t)start; tc.wb = (uint16_t)(last + 1); tc.seg = segbase ? segbase[r] + ordinal : 0; tc.prods = cur;
@@ -1427,6 +1594,7 @@ struct Heavy {
 	uint32_t cell_cap = CELL_CAP_DEFAULT, dense_min = DENSE_MIN_DEFAULT;
 	TileBases tb{};
 	uint32_t ntile = 0, ntcell = 0;
+	bool coo = false;                // the tiles also serve a STORE launch
 	unsigned long long clsprod[NCLS] = {};
 };
 
@@ -1504,6 +1672,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
 	hv.tb.enabled = !(getenv("SPSAMD_NO_TILES") && atoi(getenv("SPSAMD_NO_TILES")));
+	hv.tb.pb = hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB;
 	hv.tb.ntc = c->arena.get<uint32_t>(hv.n); hv.tb.ntl = c->arena.get<uint32_t>(hv.n);
 	hv.tb.tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); hv.tb.tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
 	fill_zero(c, hv.tb.ntc, hv.n * sizeof(uint32_t)); fill_zero(c, hv.tb.ntl, hv.n * sizeof(uint32_t));
@@ -1649,7 +1818,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	SPS_LAUNCH_CHECK();
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
-		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0, (a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0};
+		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0, 0u,
+		B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u,
+		(a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0};
 
 	// ---- segments (one per light/mid row, one per cell of a heavy row) and the heavy rows' cells
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
@@ -1657,7 +1828,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	fill_u32(c, nseg, 1u, rl.nrows);
 	Heavy hv;
 	hv.n = bins.count[8];
+	hv.coo = coo;
 	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg);
+	ep.wshift = hv.W == 8192 ? 13u : 14u;
 	uint32_t *segbase = nullptr;
 	int64_t nsegs = 0;
 	if (coo) {

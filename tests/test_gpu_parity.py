@@ -234,6 +234,21 @@ def test_rmat_full_compare(ctx, scale):
     assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
 
 
+@pytest.mark.parametrize("dbg", [0, 1024, 1536])
+def test_coo_emission_paths_agree(ctx, dbg, monkeypatch):
+    """The three ways a hash cell is emitted in column order -- bitmap rank (narrow cells), LDS radix
+    sort, bitonic network (keys wider than 32 bits) -- forced in turn through the developer switch:
+    the same tuples in the same order, against the oracle.  (dbg only selects the path.)"""
+    a = wl.rmat(15, seed=2)
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    monkeypatch.setenv("SPSAMD_DBG", str(dbg))
+    got = _dev(ctx, A, A)
+    monkeypatch.delenv("SPSAMD_DBG")
+    _check(got, want)
+    assert got[3].cells_hash > 0 and got[3].rows_mid > 0
+
+
 @pytest.mark.parametrize("tA,tB", [(".", "."), ("T", "."), (".", "T"), ("T", "T")])
 def test_heavy_rows_with_scales_and_flags(ctx, tA, tB):
     """Scale vectors (absent indices, zero scales), C != 1 and 'T' flags on an R-MAT product whose rows
