@@ -551,6 +551,16 @@ __global__ void k_row_cells(const uint32_t *binrows, uint32_t n, const uint32_t 
 	cells[i] = c;
 }
 
+// One lane's LDS fetch-add, spelled as the instruction: the compiler's atomic optimiser otherwise wraps
+// the (already wave-aggregated) add into another mbcnt / readfirstlane / multiply sequence.
+__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t *p, uint32_t v)
+{
+	uint32_t r;
+	const uint32_t a = (uint32_t)(uintptr_t)p;       // LDS byte offset = low half of the flat address of a __shared__ object
+	asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(v) : "memory");
+	return r;
+}
+
 // ---- LDS hash accumulator shared by k_hash and k_hash_tiles -----------------------------
 // T slots (power of two or 3072), at most T/2 products per cell.  The table is cleaned as it
 // is emitted (list of occupied slots), so a cell costs work proportional to its products.
@@ -584,6 +594,7 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 			col[u] = t.col;
 			pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * btup_val(t) : 0.0;
 		}
+		uint32_t slot_of[U]; uint64_t newmask[U]; uint32_t nnew = 0;
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			bool isnew = false;
@@ -599,13 +610,19 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 				}
 				if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
 			}
-			// append the newly occupied slots (one LDS atomic per wave)
-			uint64_t nm = __ballot(isnew);
-			if (nm) {
-				uint32_t base = 0;
-				if (lane_id() == 0) base = atomicAdd(s_nocc, (uint32_t)__popcll(nm));
-				base = (uint32_t)__shfl((int)base, 0, 64);
-				if (isnew) occ[base + __popcll(nm & lanemask_lt())] = (uint16_t)h;
+			slot_of[u] = h;
+			newmask[u] = __ballot(isnew);
+			nnew += (uint32_t)__popcll(newmask[u]);
+		}
+		// append the newly occupied slots of the whole step: one LDS atomic per wave and step
+		if (nnew) {                                                         // uniform
+			uint32_t base = 0;
+			if (lane_id() == 0) base = lds_add_rtn_u32(s_nocc, nnew);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if ((newmask[u] >> lane_id()) & 1ull) occ[base + __popcll(newmask[u] & lanemask_lt())] = (uint16_t)slot_of[u];
+				base += (uint32_t)__popcll(newmask[u]);
 			}
 		}
 	}
