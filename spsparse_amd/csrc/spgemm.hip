@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 
 	const unsigned w = wave_id(), lane = lane_id();
 	const unsigned g = lane / S, s = lane % S;
-	const uint32_t rix = (blockIdx.x * 4u + w) * G + g;
+	// grid-stride loop over groups of 4*G rows: the digest of a workgroup is flushed once, not per group
+	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0.0;
+	const uint32_t nvb = (nbin + 4u * G - 1u) / (4u * G);
+	for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+	const uint32_t rix = (vb * 4u + w) * G + g;
 	const bool has_row = rix < nbin;
 	const uint32_t r = has_row ? (binrows ? binrows[rix] : rix) : 0u;      // null list: the bin holds every row
 	const uint32_t beg = has_row ? m.beg[r] : 0u;
@@ -390,8 +394,10 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 			for (int d = S / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d, 64);
 			if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; }
 		}
-		digest_flush<256>(sk.digest, cnt, hash, vs, s_u64, s_f64);
+		d_cnt += cnt; d_hash += hash; d_sum += vs;
 	}
+	}
+	if (MODE == MODE_DIGEST) digest_flush<256>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
 }
 
 // ====================================================================== hash cells (LDS hash accumulator)
@@ -1564,6 +1570,8 @@ template <int MODE>
 static void launch_light(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	hipStream_t st = c->stream;
+	const unsigned cap = (unsigned)c->num_cu * 8u * 4u;           // 8 resident workgroups per CU, 4 rounds of them
+	auto grid_for = [cap](size_t n, unsigned per) { return std::min<unsigned>((unsigned)((n + per - 1) / per), cap); };
 	if (b.count[1]) { k_light<8, MODE><<<dim3(grid_for(b.count[1], 32)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[1] : nullptr, b.count[1], m, ep, sk); SPS_LAUNCH_CHECK(); }
 	if (b.count[2]) { k_light<16, MODE><<<dim3(grid_for(b.count[2], 16)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[2] : nullptr, b.count[2], m, ep, sk); SPS_LAUNCH_CHECK(); }
 	if (b.count[3]) { k_light<32, MODE><<<dim3(grid_for(b.count[3], 8)), dim3(256), 0, st>>>(b.rows ? b.rows + b.off[3] : nullptr, b.count[3], m, ep, sk); SPS_LAUNCH_CHECK(); }
