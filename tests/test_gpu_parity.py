@@ -234,6 +234,59 @@ def test_rmat_full_compare(ctx, scale):
     assert d.nnz == cnt and d.hash == h and abs(d.sum - s) <= REL * abs(s)
 
 
+def test_fuzz_shapes_flags_and_sinks(ctx):
+    """Seeded random cases over everything the boundary takes at once: rectangular and degenerate
+    shapes (1 x n, n x 1, empty rows and columns), duplicate tuples, explicit zeros, the three
+    scale vectors, C != 1, 'T' flags, duplicate policies, and the COO / permuted / digest / ordered
+    sinks -- with row products on both sides of the 64 / 4096 class boundaries and column counts on
+    both sides of one 8192-column window.  Index sets identical, values <= 1e-12 relative."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(20240917)
+    shapes = [(1, 1, 1), (1, 40, 1), (5, 1, 7), (3, 300, 9000), (60, 60, 60), (200, 17, 20000), (17, 400, 12000),
+              (2, 3000, 9000), (64, 64, 70000), (9, 2500, 40000)]
+    seen = dict(light=0, mid=0, heavy=0, hash_cells=0, dense_cells=0, empty=0)
+    for case in range(120):
+        m, k, n = shapes[(case * 7 + case // 10) % len(shapes)]
+        dens_a = rng.choice([0.02, 0.2, 0.9])
+        dens_b = rng.choice([0.002, 0.05, 0.4]) if n > 5000 else rng.choice([0.05, 0.5])
+        nnz_a = max(1, int(m * k * dens_a))
+        nnz_b = max(1, min(int(k * n * dens_b), 600000))
+        tA, tB = rng.choice([".", "T"]), rng.choice([".", "T"])
+        sa = (k, m) if tA == "T" else (m, k)
+        sb = (n, k) if tB == "T" else (k, n)
+        A = _rand_mat(rng, sa, nnz_a, zeros=bool(case % 3 == 0), positive=bool(case % 4))
+        B = _rand_mat(rng, sb, nnz_b, zeros=bool(case % 5 == 0), positive=bool(case % 4))
+        kw = dict(tA=tA, tB=tB, C_=float(rng.choice([1.0, -0.5, 3.0])),
+                  duplicate_policy=int(rng.choice([capi.ADD, capi.LEAVE_ALONE, capi.REPLACE])))
+        if case % 2:
+            kw["scalei"] = _rand_vec(rng, m)
+        if case % 3 == 1:
+            kw["scalej"] = _rand_vec(rng, k)
+        if case % 4 == 2:
+            kw["scalek"] = _rand_vec(rng, n)
+        okw = dict(kw)
+        want = orc.multiply(A, B, rowwise=True, nthreads=8, **okw)
+        mixed = not bool(case % 4)                              # values of both signs: sums cancel
+        ordered = mixed or case % 4 == 3
+        got = _dev(ctx, A, B, flags=capi.SINK_ORDERED if ordered else 0, **kw)
+        _check(got, want, exact=ordered)
+        if mixed:                                               # default (arrival-order) sums: same index set, values to rounding
+            g2 = _dev(ctx, A, B, **kw)
+            assert np.array_equal(g2[0], want[0]) and np.array_equal(g2[1], want[1])
+            assert np.allclose(g2[2], want[2], rtol=1e-9, atol=1e-9)
+        assert (got[3].shape0, got[3].shape1) == (m, n)
+        r_ = got[3]
+        seen["light"] += r_.rows_light > 0; seen["mid"] += r_.rows_mid > 0; seen["heavy"] += r_.rows_heavy > 0
+        seen["hash_cells"] += r_.cells_hash > 0; seen["dense_cells"] += r_.cells_dense > 0; seen["empty"] += r_.nnz == 0
+        pi, pj, pv, pres = _dev(ctx, A, B, flags=capi.SINK_PERMUTE, **kw)
+        assert np.array_equal(pi, got[1]) and np.array_equal(pj, got[0]) and (pres.shape0, pres.shape1) == (n, m)
+        _, _, _, d = _dev(ctx, A, B, sink=capi.SINK_DIGEST, **kw)
+        cnt, ssum, h = orc.digest(*want[:3])
+        assert d.nnz == cnt and d.hash == h
+    print("fuzz coverage:", seen)
+    assert seen["light"] >= 5 and seen["mid"] >= 5 and seen["heavy"] >= 5 and seen["hash_cells"] >= 3 and seen["dense_cells"] >= 3
+
+
 @pytest.mark.parametrize("dbg", [0, 1024, 1536])
 def test_coo_emission_paths_agree(ctx, dbg, monkeypatch):
     """The three ways a hash cell is emitted in column order -- bitmap rank (narrow cells), LDS radix
