@@ -1152,17 +1152,29 @@ __global__ void k_bwin_fill(const int32_t *brow, const int32_t *bcol, const uint
 	for (int ww = wprev + 1; ww <= w; ++ww) bwin[(uint64_t)k * nwin1 + ww] = e;
 }
 
+// Tuples of B row k in window w as 16 bits (<= W <= 16384): half the bytes of the offset pairs for
+// the histogram below, which reads one whole row of this table per A tuple of a heavy row.
+__global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwin, uint16_t *cnt)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t total = nrowb * nwin, stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < total; i += stride) {
+		const uint64_t k = i / nwin, w = i - k * nwin;
+		const uint32_t *bw = bwin + k * (nwin + 1) + w;
+		cnt[i] = (uint16_t)(bw[1] - bw[0]);
+	}
+}
+
 // Per heavy row: products per column window.  One workgroup per row; lanes run
-// over the windows of one A tuple (coalesced reads of its bwin row).
+// over the windows of one A tuple (coalesced reads of its row of the count table).
 constexpr int WH_NT = 256;
 constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
-__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint32_t *bwin,
+__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
 	uint32_t nwin, uint32_t *winprod)
 {
 	__shared__ uint32_t s_cnt[WH_MAXW];
 	const uint32_t h = blockIdx.x, r = hrows[h];
 	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
-	const uint32_t nwin1 = nwin + 1;
 	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) s_cnt[w] = 0;
 	__syncthreads();
 	// sub-groups of threads take different tuples when there are fewer windows than threads
@@ -1173,38 +1185,30 @@ __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint3
 	if (nsub > 1) {
 		uint32_t cnt = 0;
 		if (w0 < nwin) {
-			// four A tuples per step: their index rows are fetched with independent loads
+			// four A tuples per step: their table rows are fetched with independent loads
 			uint32_t e = beg + sub;
 			for (; e + 3 * nsub < end; e += 4 * nsub) {
-				const uint32_t *b0 = bwin + (uint64_t)m.acol[e] * nwin1 + w0;
-				const uint32_t *b1 = bwin + (uint64_t)m.acol[e + nsub] * nwin1 + w0;
-				const uint32_t *b2 = bwin + (uint64_t)m.acol[e + 2 * nsub] * nwin1 + w0;
-				const uint32_t *b3 = bwin + (uint64_t)m.acol[e + 3 * nsub] * nwin1 + w0;
-				uint32_t x0 = b0[0], y0 = b0[1], x1 = b1[0], y1 = b1[1], x2 = b2[0], y2 = b2[1], x3 = b3[0], y3 = b3[1];
-				cnt += (y0 - x0) + (y1 - x1) + (y2 - x2) + (y3 - x3);
+				const uint32_t x0 = wcnt[(uint64_t)m.acol[e] * nwin + w0];
+				const uint32_t x1 = wcnt[(uint64_t)m.acol[e + nsub] * nwin + w0];
+				const uint32_t x2 = wcnt[(uint64_t)m.acol[e + 2 * nsub] * nwin + w0];
+				const uint32_t x3 = wcnt[(uint64_t)m.acol[e + 3 * nsub] * nwin + w0];
+				cnt += x0 + x1 + x2 + x3;
 			}
-			for (; e < end; e += nsub) {
-				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
-				cnt += bw[w0 + 1] - bw[w0];
-			}
+			for (; e < end; e += nsub) cnt += wcnt[(uint64_t)m.acol[e] * nwin + w0];
 		}
 		if (w0 < nwin && cnt) atomicAdd(&s_cnt[w0], cnt);
 	} else {
 		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) {
 			uint32_t cnt = 0;
 			uint32_t e = beg;
-			for (; e + 3 < end; e += 4) {               // four index rows in flight
-				const uint32_t *b0 = bwin + (uint64_t)m.acol[e] * nwin1 + w;
-				const uint32_t *b1 = bwin + (uint64_t)m.acol[e + 1] * nwin1 + w;
-				const uint32_t *b2 = bwin + (uint64_t)m.acol[e + 2] * nwin1 + w;
-				const uint32_t *b3 = bwin + (uint64_t)m.acol[e + 3] * nwin1 + w;
-				uint32_t x0 = b0[0], y0 = b0[1], x1 = b1[0], y1 = b1[1], x2 = b2[0], y2 = b2[1], x3 = b3[0], y3 = b3[1];
-				cnt += (y0 - x0) + (y1 - x1) + (y2 - x2) + (y3 - x3);
+			for (; e + 3 < end; e += 4) {               // four table rows in flight
+				const uint32_t x0 = wcnt[(uint64_t)m.acol[e] * nwin + w];
+				const uint32_t x1 = wcnt[(uint64_t)m.acol[e + 1] * nwin + w];
+				const uint32_t x2 = wcnt[(uint64_t)m.acol[e + 2] * nwin + w];
+				const uint32_t x3 = wcnt[(uint64_t)m.acol[e + 3] * nwin + w];
+				cnt += x0 + x1 + x2 + x3;
 			}
-			for (; e < end; ++e) {
-				const uint32_t *bw = bwin + (uint64_t)m.acol[e] * nwin1;
-				cnt += bw[w + 1] - bw[w];
-			}
+			for (; e < end; ++e) cnt += wcnt[(uint64_t)m.acol[e] * nwin + w];
 			s_cnt[w] = cnt;
 		}
 	}
@@ -1685,7 +1689,10 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	SPS_LAUNCH_CHECK();
 	hv.rows = bins.rows + bins.off[8];
 	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
-	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, hv.bwin, hv.nwin, hv.winprod);
+	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * hv.nwin);
+	k_bwin_counts<<<dim3(4096), dim3(256), 0, st>>>(hv.bwin, nrowb, hv.nwin, wcnt);
+	SPS_LAUNCH_CHECK();
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, hv.winprod);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) {
 		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
