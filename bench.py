@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--scale", type=int, default=20, help="R-MAT scale (cfg2 = 20, cfg4 = 23)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=14, help="R-MAT scale of the bounded CPU sample")
+    ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
     ap.add_argument("--calibrate", type=int, default=2,
                     help="N>1 setup: measure/rebalance rounds of the row-block boundaries (0: cost estimate only)")
     ap.add_argument("--dist-path", action="store_true",
