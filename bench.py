@@ -56,7 +56,9 @@ def cpu_baseline(scale, seed):
     """The CPU port of the reference algorithm (oracle/spsparse_oracle.c,
     orc_multiply_mm: sorted rows x sorted columns, leap-frog merge joins --
     multiply_sparse.hpp:192-246) timed on one host core on a bounded sample of
-    the same workload.  Reported beside the GPU number, never the target."""
+    the same workload.  Reported beside the GPU number, never the target.
+    Also timed: the same port on cfg1, and the row-wise
+    checker at one thread and at every host core."""
     from oracle import binding as orc
     from spsparse_amd import workloads as wl
     A = orc.Mat(*wl.rmat(scale, seed))
@@ -66,11 +68,31 @@ def cpu_baseline(scale, seed):
     t = time.time()
     i2, _, _, _ = orc.multiply(A, A, rowwise=True)
     dt2 = time.time() - t
+    ncores = os.cpu_count() or 1
+    t = time.time()
+    orc.multiply(A, A, rowwise=True, nthreads=ncores)
+    dt3 = time.time() - t
     assert len(i) == len(i2)
+    a1, b1 = wl.random_rows(1000, 10, seed=1), wl.random_rows(1000, 10, seed=2)
+    A1, B1 = orc.Mat(*a1), orc.Mat(*b1)
+    t = time.time()
+    c1 = orc.multiply(A1, B1)
+    dt1 = time.time() - t
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": len(v) / dt, "unit": "nnz(C)/s", "cores": 1, "kind": "port",
             "sample": "R-MAT scale-%d A*A (same generator, %d tuples -> nnz(C)=%d) in %.1f s; the reference's "
                       "inner-product algorithm is Theta(rows*cols): extrapolated to scale-20 it needs days" % (scale, A.nnz, len(v), dt),
-            "rowwise_port_value": len(v) / dt2}
+            "rowwise_port_value": len(v) / dt2,
+            "rowwise_port_all_cores_value": len(v) / dt3, "host_cores": ncores, "cpu_model": model,
+            "cfg1_value": len(c1[2]) / dt1, "cfg1_sample": "1k x 1k, 10 tuples per row, A*B: nnz(C)=%d in %.3f s" % (len(c1[2]), dt1)}
 
 
 def main():
