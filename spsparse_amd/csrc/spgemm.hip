@@ -39,6 +39,12 @@ enum { MODE_COUNT = 0, MODE_STORE = 1, MODE_DIGEST = 2 };
 
 constexpr int NBIN = 9;          // 0 none | 1..4 light (S = 8,16,32,64) | 5..7 mid (T = 1024,4096,8192) | 8 heavy
 constexpr uint32_t MID_MAX = 4096;
+#ifndef DENSE_U
+#define DENSE_U 1
+#endif
+#ifndef HASH_U
+#define HASH_U 4
+#endif
 constexpr int DIGEST_SLOTS = 1024;
 
 struct EmitParams {
@@ -585,7 +591,7 @@ template <int T, int NT, int PB, int MODE>
 __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t p0, uint32_t p1, uint32_t pb, const RowMeta &m,
 	int32_t *h_key, double *h_val, uint16_t *occ, uint32_t *s_nocc)
 {
-	constexpr int U = 4;
+	constexpr int U = HASH_U;
 	const unsigned tid = threadIdx.x;
 	for (uint32_t pbase = p0; pbase < p1; pbase += NT * U) {
 		int32_t col[U]; double pv[U]; bool ok[U];
@@ -1440,27 +1446,42 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 				// U products per thread and step: all B loads of a step are issued before the first
 				// is used (the loop is bound by load latency, not by bandwidth or issue rate).
 				// A thread past the end re-reads the last product with weight 0.
-				constexpr int U = 2;
-				for (uint32_t p0 = pb + tid; p0 < pe; p0 += NT * U) {
-					uint32_t bp[U]; double av[U];
+				// Software pipelined over the steps: the segment lookups of step s+1 (two dependent LDS
+				// round trips) are issued while the B loads of step s are in flight, so a step costs
+				// max(lookup, gather) + accumulate instead of their sum.
+				constexpr int U = DENSE_U;
+				const uint32_t nsteps = (pe - pb + NT * U - 1) / (NT * U);      // uniform
+				uint32_t bp[U]; double av[U];
+				auto lookup = [&](uint32_t step, uint32_t (&obp)[U], double (&oav)[U]) {
 #pragma unroll
 					for (int u = 0; u < U; ++u) {
-						uint32_t p = p0 + u * NT;
+						uint32_t p = pb + step * (NT * U) + u * NT + tid;
 						const bool ok = p < pe;
 						p = ok ? p : pe - 1;
 						uint32_t q = expand_lookup(X, p, pb);
-						bp[u] = X.cstart[q] + (p - X.cpref[q]);
-						av[u] = ok ? X.caval[q] : 0.0;
+						obp[u] = X.cstart[q] + (p - X.cpref[q]);
+						oav[u] = ok ? X.caval[q] : 0.0;
 					}
+				};
+				lookup(0, bp, av);
+				for (uint32_t step = 0; step < nsteps; ++step) {
 					uint32_t col[U]; double bv[U];
 #pragma unroll
 					for (int u = 0; u < U; ++u) { const BTup t = m.btup[bp[u]]; col[u] = (uint32_t)t.col; bv[u] = btup_val(t); }
+					uint32_t nbp[U]; double nav[U];
+					if (step + 1 < nsteps) lookup(step + 1, nbp, nav);          // uniform branch
+					else {
+#pragma unroll
+						for (int u = 0; u < U; ++u) { nbp[u] = bp[u]; nav[u] = 0.0; }
+					}
 #pragma unroll
 					for (int u = 0; u < U; ++u) {
 						uint32_t slot = col[u] - wbase;
 						if (MODE == MODE_COUNT) acc[slot] = 1.0;    // structural: touched
 						else atomicAdd(&acc[slot], av[u] * bv[u]);
 					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) { bp[u] = nbp[u]; av[u] = nav[u]; }
 				}
 				lds_barrier();
 			}
