@@ -190,18 +190,28 @@ extern "C" int spsamd_result_fetch(spsamd_ctx *c, const spsamd_result *res, spsa
 		if (res->nnz == 0) return SPSAMD_OK;
 		if (!res->idx0 || !res->val) throw Error{SPSAMD_EINVAL, "result has no COO tuples (DIGEST sink?)"};
 		SPS_HIP(hipSetDevice(c->device));
+		// chunks of 2^20 tuples through two pinned staging buffers: the copy of chunk k+1 runs while the
+		// callback consumes chunk k (the callback, one ret.add() per tuple upstream, is the slow side)
 		const size_t chunk = size_t(1) << 20;
-		char *h = (char *)c->host_staging(chunk * 16);
-		int32_t *hi = (int32_t *)h, *hj = (int32_t *)(h + chunk * 4);
-		double *hv = (double *)(h + chunk * 8);
-		for (uint64_t o = 0; o < res->nnz; o += chunk) {
+		char *h = (char *)c->host_staging(2 * chunk * 16);
+		hipEvent_t ev[2] = {c->ev[8], c->ev[9]};
+		auto issue = [&](uint64_t o, int b) {
 			size_t n = (size_t)std::min<uint64_t>(chunk, res->nnz - o);
-			SPS_HIP(hipMemcpyAsync(hi, res->idx0 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
-			if (res->idx1) SPS_HIP(hipMemcpyAsync(hj, res->idx1 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
-			SPS_HIP(hipMemcpyAsync(hv, res->val + o, n * 8, hipMemcpyDeviceToHost, c->stream));
-			SPS_HIP(hipStreamSynchronize(c->stream));
-			int rc = cb(user, hi, res->idx1 ? hj : nullptr, hv, n);
-			if (rc) return rc;
+			char *hb = h + (size_t)b * chunk * 16;
+			SPS_HIP(hipMemcpyAsync(hb, res->idx0 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
+			if (res->idx1) SPS_HIP(hipMemcpyAsync(hb + chunk * 4, res->idx1 + o, n * 4, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipMemcpyAsync(hb + chunk * 8, res->val + o, n * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipEventRecord(ev[b], c->stream));
+		};
+		issue(0, 0);
+		int b = 0;
+		for (uint64_t o = 0; o < res->nnz; o += chunk, b ^= 1) {
+			size_t n = (size_t)std::min<uint64_t>(chunk, res->nnz - o);
+			if (o + chunk < res->nnz) issue(o + chunk, b ^ 1);
+			SPS_HIP(hipEventSynchronize(ev[b]));
+			char *hb = h + (size_t)b * chunk * 16;
+			int rc = cb(user, (int32_t *)hb, res->idx1 ? (int32_t *)(hb + chunk * 4) : nullptr, (double *)(hb + chunk * 8), n);
+			if (rc) { SPS_HIP(hipStreamSynchronize(c->stream)); return rc; }
 		}
 		return SPSAMD_OK;
 	)
