@@ -287,6 +287,38 @@ def test_fuzz_shapes_flags_and_sinks(ctx):
     assert seen["light"] >= 5 and seen["mid"] >= 5 and seen["heavy"] >= 5 and seen["hash_cells"] >= 3 and seen["dense_cells"] >= 3
 
 
+def test_two_contexts_on_two_threads(ctx):
+    """SURVEY 8b 'Threading': the library must be callable concurrently on different handles.
+    Two host threads, one context (HIP stream, arena) each, multiply different operands at once."""
+    import threading
+    from spsparse_amd import capi
+    cases = []
+    for seed in (3, 4):
+        a = wl.rmat(13, seed=seed)
+        A = orc.Mat(*a)
+        cases.append((A, orc.multiply(A, A, rowwise=True, nthreads=4)))
+    errors = []
+
+    def work(A, want):
+        try:
+            c = capi.Context(0)
+            for _ in range(5):
+                _check(_dev(c, A, A), want)
+                _, _, _, d = _dev(c, A, A, sink=capi.SINK_DIGEST)
+                cnt, _, h = orc.digest(*want[:3])
+                assert d.nnz == cnt and d.hash == h
+            c.close()
+        except Exception as e:          # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=c) for c in cases]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("dbg", [0, 1024, 1536])
 def test_coo_emission_paths_agree(ctx, dbg, monkeypatch):
     """The three ways a hash cell is emitted in column order -- bitmap rank (narrow cells), LDS radix
