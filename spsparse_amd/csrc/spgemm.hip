@@ -1159,64 +1159,53 @@ __global__ void k_bwin_fill(const int32_t *brow, const int32_t *bcol, const uint
 }
 
 // Tuples of B row k in window w as 16 bits (<= W <= 16384): half the bytes of the offset pairs for
-// the histogram below, which reads one whole row of this table per A tuple of a heavy row.
-__global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwin, uint16_t *cnt)
+// the histogram below, which reads one whole row of this table per A tuple of a heavy row.  Rows
+// are padded to an even number of entries (nwp) so that two windows are read as one 32-bit word.
+__global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwin, uint32_t nwp, uint16_t *cnt)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t total = nrowb * nwin, stride = (uint64_t)gridDim.x * blockDim.x;
+	const uint64_t total = nrowb * nwp, stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < total; i += stride) {
-		const uint64_t k = i / nwin, w = i - k * nwin;
-		const uint32_t *bw = bwin + k * (nwin + 1) + w;
-		cnt[i] = (uint16_t)(bw[1] - bw[0]);
+		const uint64_t k = i / nwp, w = i - k * nwp;
+		uint16_t v = 0;
+		if (w < nwin) { const uint32_t *bw = bwin + k * (nwin + 1) + w; v = (uint16_t)(bw[1] - bw[0]); }
+		cnt[i] = v;
 	}
 }
 
-// Per heavy row: products per column window.  One workgroup per row; lanes run
-// over the windows of one A tuple (coalesced reads of its row of the count table).
+// Per heavy row: products per column window.  One workgroup per row; a thread owns a PAIR of
+// windows (one 32-bit load per A tuple), sub-groups of threads take different tuples and every
+// thread keeps 8 tuples in flight: the longest hub row (tens of thousands of tuples, one
+// workgroup) sets this kernel's time.
 constexpr int WH_NT = 256;
 constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
 __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
-	uint32_t nwin, uint32_t *winprod)
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod)
 {
 	__shared__ uint32_t s_cnt[WH_MAXW];
 	const uint32_t h = blockIdx.x, r = hrows[h];
 	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
-	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) s_cnt[w] = 0;
+	for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
 	__syncthreads();
-	// sub-groups of threads take different tuples when there are fewer windows than threads
-	uint32_t wpad = 1;
-	while (wpad < nwin && wpad < WH_NT) wpad <<= 1;
-	const uint32_t nsub = wpad < WH_NT ? WH_NT / wpad : 1;
-	const uint32_t sub = threadIdx.x / wpad, w0 = threadIdx.x % wpad;
-	if (nsub > 1) {
-		uint32_t cnt = 0;
-		if (w0 < nwin) {
-			// four A tuples per step: their table rows are fetched with independent loads
-			uint32_t e = beg + sub;
-			for (; e + 3 * nsub < end; e += 4 * nsub) {
-				const uint32_t x0 = wcnt[(uint64_t)m.acol[e] * nwin + w0];
-				const uint32_t x1 = wcnt[(uint64_t)m.acol[e + nsub] * nwin + w0];
-				const uint32_t x2 = wcnt[(uint64_t)m.acol[e + 2 * nsub] * nwin + w0];
-				const uint32_t x3 = wcnt[(uint64_t)m.acol[e + 3 * nsub] * nwin + w0];
-				cnt += x0 + x1 + x2 + x3;
-			}
-			for (; e < end; e += nsub) cnt += wcnt[(uint64_t)m.acol[e] * nwin + w0];
+	const uint32_t npair = nwp >> 1;
+	const uint32_t *tab = (const uint32_t *)wcnt;                       // row k: npair words
+	uint32_t ppad = 1;
+	while (ppad < npair && ppad < WH_NT) ppad <<= 1;
+	const uint32_t nsub = ppad < WH_NT ? WH_NT / ppad : 1;
+	const uint32_t sub = threadIdx.x / ppad, p0 = threadIdx.x % ppad;
+	for (uint32_t p = p0; p < npair; p += ppad) {                       // one pass unless there are more than 256 pairs
+		uint32_t c0 = 0, c1 = 0;
+		uint32_t e = beg + sub;
+		for (; e + 7 * nsub < end; e += 8 * nsub) {
+			uint32_t x[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) x[u] = tab[(uint64_t)m.acol[e + u * nsub] * npair + p];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { c0 += x[u] & 0xFFFFu; c1 += x[u] >> 16; }
 		}
-		if (w0 < nwin && cnt) atomicAdd(&s_cnt[w0], cnt);
-	} else {
-		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) {
-			uint32_t cnt = 0;
-			uint32_t e = beg;
-			for (; e + 3 < end; e += 4) {               // four table rows in flight
-				const uint32_t x0 = wcnt[(uint64_t)m.acol[e] * nwin + w];
-				const uint32_t x1 = wcnt[(uint64_t)m.acol[e + 1] * nwin + w];
-				const uint32_t x2 = wcnt[(uint64_t)m.acol[e + 2] * nwin + w];
-				const uint32_t x3 = wcnt[(uint64_t)m.acol[e + 3] * nwin + w];
-				cnt += x0 + x1 + x2 + x3;
-			}
-			for (; e < end; ++e) cnt += wcnt[(uint64_t)m.acol[e] * nwin + w];
-			s_cnt[w] = cnt;
-		}
+		for (; e < end; e += nsub) { const uint32_t x = tab[(uint64_t)m.acol[e] * npair + p]; c0 += x & 0xFFFFu; c1 += x >> 16; }
+		if (nsub > 1) { if (c0) atomicAdd(&s_cnt[2 * p], c0); if (c1) atomicAdd(&s_cnt[2 * p + 1], c1); }
+		else { s_cnt[2 * p] = c0; s_cnt[2 * p + 1] = c1; }
 	}
 	__syncthreads();
 	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
@@ -1710,10 +1699,11 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	SPS_LAUNCH_CHECK();
 	hv.rows = bins.rows + bins.off[8];
 	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
-	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * hv.nwin);
-	k_bwin_counts<<<dim3(4096), dim3(256), 0, st>>>(hv.bwin, nrowb, hv.nwin, wcnt);
+	const uint32_t nwp = (hv.nwin + 1u) & ~1u;
+	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * nwp);
+	k_bwin_counts<<<dim3(4096), dim3(256), 0, st>>>(hv.bwin, nrowb, hv.nwin, nwp, wcnt);
 	SPS_LAUNCH_CHECK();
-	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, hv.winprod);
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) {
 		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
