@@ -1328,7 +1328,9 @@ __global__ void k_cell_keys(const Cell *cells, uint32_t n, int by_size, uint64_t
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint64_t w = cells[i].wa;
-	keys[i] = by_size ? ((w << 32) | (uint64_t)(0xFFFFFFFFu - cells[i].prods)) : w;
+	// size in units of 256 products, 16 bits (cells beyond 2^24 products rank equal): a 16-bit minor key = 2 sort passes
+	const uint32_t sz = min(cells[i].prods >> 8, 0xFFFFu);
+	keys[i] = by_size ? ((w << 16) | (uint64_t)(0xFFFFu - sz)) : w;
 }
 
 __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n, Cell *dst)
@@ -1734,6 +1736,8 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase)
 {
 	hipStream_t st = c->stream;
+	int wbits = 1;                                   // bits of a window index: the cell lists are sorted on as few digits as needed
+	while ((1u << wbits) < hv.nwin) ++wbits;
 	CellLists lists;
 	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
 	hv.tb.tcells = c->arena.get<TCell>(hv.ntcell ? hv.ntcell : 1);
@@ -1746,7 +1750,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
 		k_tile_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, nd, k0);
 		SPS_LAUNCH_CHECK();
-		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, 12);
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, wbits);
 		Tile *sorted = c->arena.get<Tile>(nd);
 		k_gather_tiles<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, where ? p1 : p0, nd, sorted);
 		SPS_LAUNCH_CHECK();
@@ -1759,7 +1763,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
 		k_cell_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == CLS_DENSE, k0);
 		SPS_LAUNCH_CHECK();
-		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == CLS_DENSE ? 44 : 12);
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == CLS_DENSE ? 16 + wbits : wbits);
 		Cell *sorted = c->arena.get<Cell>(nd);
 		k_gather_cells<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], where ? p1 : p0, nd, sorted);
 		SPS_LAUNCH_CHECK();
