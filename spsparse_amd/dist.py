@@ -49,7 +49,7 @@ def row_cost(row_products_):
     return (P * w).round().to(torch.int64)
 
 
-def rebalance_bounds(bounds, cost_prefix, block_ms, fixed_ms=0.0):
+def rebalance_bounds(bounds, cost_prefix, block_ms, fixed_ms=0.0, min_gain=0.0):
     """New contiguous row-block boundaries from MEASURED per-block times.
 
     bounds       current boundaries [0, b1, ..., n]
@@ -60,9 +60,14 @@ def rebalance_bounds(bounds, cost_prefix, block_ms, fixed_ms=0.0):
     Inside a block the measured time (less fixed_ms) is spread over its rows in proportion to the
     cost estimate, which gives a piecewise-linear cumulative time over the rows; the new
     boundaries cut it into equal parts.  One or two rounds (measure, rebalance) make the blocks
-    equal in time even where the estimate is off by a block-dependent factor."""
+    equal in time even where the estimate is off by a block-dependent factor.  With min_gain > 0 the
+    boundaries are left alone when the slowest block is less than that fraction above the mean (a
+    rebalance on timer noise can only make things worse)."""
     nparts = len(bounds) - 1
     n = bounds[-1]
+    mean = sum(float(t) for t in block_ms) / max(nparts, 1)
+    if min_gain > 0.0 and mean > 0.0 and max(float(t) for t in block_ms) / mean - 1.0 < min_gain:
+        return list(bounds)                      # already balanced within the measurement noise: leave it
     cp = cost_prefix.to(torch.float64)
     var = [max(float(t) - fixed_ms, 1e-9) for t in block_ms]
     total = sum(var)

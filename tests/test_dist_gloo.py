@@ -138,6 +138,8 @@ def test_rebalance_from_measured_times():
     # equal measured times leave the boundaries where they are (up to one row)
     b2 = sd.rebalance_bounds(b, cp, [1.0] * world)
     assert all(abs(x - y) <= 1 for x, y in zip(b2, b))
+    # within the noise threshold nothing moves at all
+    assert sd.rebalance_bounds(b, cp, [1.0, 1.02] + [1.0] * (world - 2), min_gain=0.03) == b
 
 
 def test_balanced_bounds_edge_cases():
