@@ -245,7 +245,7 @@ def test_fuzz_shapes_flags_and_sinks(ctx):
     from spsparse_amd import capi
     rng = np.random.default_rng(int(os.environ.get("SPSAMD_FUZZ_SEED", "20240917")))      # other seeds: soak runs
     shapes = [(1, 1, 1), (1, 40, 1), (5, 1, 7), (3, 300, 9000), (60, 60, 60), (200, 17, 20000), (17, 400, 12000),
-              (2, 3000, 9000), (64, 64, 70000), (9, 2500, 40000)]
+              (2, 3000, 9000), (64, 64, 70000), (9, 2500, 40000), (30, 2000, 3000000), (4, 5000, 2500000)]   # last two: 16384-column windows
     seen = dict(light=0, mid=0, heavy=0, hash_cells=0, dense_cells=0, empty=0)
     for case in range(120):
         m, k, n = shapes[(case * 7 + case // 10) % len(shapes)]
