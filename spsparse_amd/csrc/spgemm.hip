@@ -170,7 +170,7 @@ __global__ void k_apply_scalej(const int32_t *acol, const double *aval, uint32_t
 	else { acol2[e] = k; aval2[e] = aval[e] * sval[q]; }
 }
 
-struct BinCounters { unsigned long long rows[NBIN]; unsigned long long prods[NBIN]; unsigned long long tuples[NBIN]; };
+struct BinCounters { unsigned long long rows[NBIN]; unsigned long long prods[NBIN]; unsigned long long tuples[NBIN]; unsigned long long too_big; };
 
 __device__ __forceinline__ int bin_of(uint32_t P)
 {
@@ -210,7 +210,11 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int
 			La = b1 - b0;
 			if (La <= 8) {                          // short row: its tuples' lengths are one or two cache lines
 				for (uint32_t e = b0; e < b1; ++e) P += elen[e];
-			} else P = (uint32_t)(pref[b1] - pref[b0]);
+			} else {
+				const int64_t d = pref[b1] - pref[b0];
+				if (d > 0xFFFFFFFFll) atomicAdd(&bc->too_big, 1ull);    // the per-row counters are 32 bits wide: reported by the host
+				P = (uint32_t)d;
+			}
 			if (si_pos) {
 				int32_t q = si_pos[id[r]];
 				if (q < 0 || si_val[q] == 0) P = 0;
@@ -1826,6 +1830,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		a.si.present ? a.si.pos : nullptr, a.si.val, rprod, rbin, bc);
 	SPS_LAUNCH_CHECK();
 	BinCounters hbc = read_back(c, bc);
+	if (hbc.too_big) throw Error{SPSAMD_EINVAL, "an output row with more than 2^32-1 scalar products is not supported"};
 
 	Bins bins;
 	BinOffsets bo;
