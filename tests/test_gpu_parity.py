@@ -289,6 +289,29 @@ def test_fuzz_shapes_flags_and_sinks(ctx):
     assert seen["light"] >= 5 and seen["mid"] >= 5 and seen["heavy"] >= 5 and seen["hash_cells"] >= 3 and seen["dense_cells"] >= 3
 
 
+def test_bench_dist_path_matches_plain_path():
+    """bench.py's N>1 code (row block, calibration rounds, all-to-allv of B panels over RCCL, digest
+    reduction) rehearsed on a 1-rank NCCL group: same digest as the plain single-GPU path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+              "--no-cpu-baseline", "--scale", "16"]
+    outs = []
+    for extra in ([], ["--dist-path", "--calibrate", "1"]):
+        p = subprocess.run(common + extra, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    assert a["config"]["nnz_c"] == b["config"]["nnz_c"] and a["config"]["digest"]["hash"] == b["config"]["digest"]["hash"]
+    assert abs(a["config"]["digest"]["sum"] - b["config"]["digest"]["sum"]) <= 1e-12 * abs(a["config"]["digest"]["sum"])
+    assert b["config"]["calibration_local_ms"] and len(b["config"]["calibration_local_ms"][0]) == 1
+    for d in outs:
+        assert d["unit"] == "nnz(C)/s" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
 def test_two_contexts_on_two_threads(ctx):
     """SURVEY 8b 'Threading': the library must be callable concurrently on different handles.
     Two host threads, one context (HIP stream, arena) each, multiply different operands at once."""
