@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
     ap.add_argument("--calibrate", type=int, default=2,
                     help="N>1 setup: measure/rebalance rounds of the row-block boundaries (0: cost estimate only)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 rehearsal on ONE GPU: every rank uses cuda:0, collectives run over gloo on host copies "
+                         "(exercises the multi-rank logic where only one GPU is available; not a measurement)")
     ap.add_argument("--dist-path", action="store_true",
                     help="with --gpus 1: run the row-block + all-to-allv path on a 1-rank group (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -109,12 +112,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.dist_path
+    coll_dev = torch.device("cpu") if args.rehearse_gloo else dev      # where the collectives' tensors live
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world == 1:
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        elif world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -181,7 +189,12 @@ def main():
             a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n)))
             torch.cuda.synchronize()
             t_b = time.perf_counter()
-            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
+            if args.rehearse_gloo:
+                h0, h1, hv = a0.cpu(), a1.cpu(), av.cpu()
+                p0, p1, pv, remote = sd.exchange_b_panels(h1, h0, h1, hv, bounds_now[0], n)
+                p0, p1, pv = p0.to(dev), p1.to(dev), pv.to(dev)
+            else:
+                p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
             Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
             Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
             torch.cuda.synchronize()
@@ -198,10 +211,10 @@ def main():
             blk = take_block(bounds_now[0])
             run_block(blk)
             local_ms = min(run_block(blk)[2] for _ in range(3))        # best of three: the timer noise is about 1 ms
-            mine = torch.tensor([local_ms], dtype=torch.float64, device=dev)
-            every = torch.empty(world, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(every, mine)
-            times = [float(x) for x in every.tolist()]
+            mine = torch.tensor([local_ms], dtype=torch.float64, device=coll_dev)
+            every = [torch.empty(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+            dist.all_gather(every, mine)
+            times = [float(x[0]) for x in every]
             calib.append([round(x, 2) for x in times])
             bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times, min_gain=0.03)
             del blk
@@ -231,13 +244,13 @@ def main():
 
     res, remote = results[-1]
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
-        stats = torch.tensor([res.nnz_a, res.products, remote], dtype=torch.int64, device=dev)
+        stats = torch.tensor([res.nnz_a, res.products, remote], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(stats)
         nnz_a, products, remote_total = [int(x) for x in stats.tolist()]
-        nnz_c, vsum, vhash = sd.reduce_digest(int(res.nnz), float(res.sum), int(res.hash), dev)
+        nnz_c, vsum, vhash = sd.reduce_digest(int(res.nnz), float(res.sum), int(res.hash), coll_dev)
     else:
         nnz_a, products, remote_total = int(res.nnz_a), int(res.products), 0
         nnz_c, vsum, vhash = int(res.nnz), float(res.sum), int(res.hash)

@@ -312,6 +312,34 @@ def test_bench_dist_path_matches_plain_path():
         assert d["unit"] == "nnz(C)/s" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """The multi-rank control flow of bench.py with REAL second rank: two processes (torch.distributed.run),
+    both on cuda:0, collectives over gloo on host copies (--rehearse-gloo).  Distinct row blocks per rank,
+    calibration + rebalancing, panel exchange between different owners, digest reduction: the whole-job
+    digest must equal the single-GPU one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--scale", "16"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + base, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    one = json.loads(p.stdout.strip().splitlines()[-1])
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29588", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--rehearse-gloo", "--calibrate", "2"] + base,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["remote_panel_tuples"] > 0
+    assert two["config"]["nnz_c"] == one["config"]["nnz_c"] and two["config"]["digest"]["hash"] == one["config"]["digest"]["hash"]
+    assert two["config"]["products"] == one["config"]["products"] and two["config"]["nnz_a"] == one["config"]["nnz_a"]
+    assert abs(two["config"]["digest"]["sum"] - one["config"]["digest"]["sum"]) <= 1e-12 * abs(one["config"]["digest"]["sum"])
+    assert len(two["config"]["calibration_local_ms"]) == 2 and len(two["config"]["calibration_local_ms"][0]) == 2
+
+
 def test_two_contexts_on_two_threads(ctx):
     """SURVEY 8b 'Threading': the library must be callable concurrently on different handles.
     Two host threads, one context (HIP stream, arena) each, multiply different operands at once."""
