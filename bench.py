@@ -100,6 +100,8 @@ def cpu_baseline(scale, seed):
 
 def main():
     args = parse()
+    # dmabuf IPC for RCCL: must be in the environment before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from spsparse_amd import capi
@@ -119,7 +121,6 @@ def main():
     use_dist = world > 1 or args.dist_path
     coll_dev = torch.device("cpu") if args.rehearse_gloo else dev      # where the collectives' tensors live
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.rehearse_gloo:
             dist.init_process_group("gloo")
         elif world == 1:
