@@ -38,7 +38,10 @@ namespace spsamd {
 enum { MODE_COUNT = 0, MODE_STORE = 1, MODE_DIGEST = 2 };
 
 constexpr int NBIN = 9;          // 0 none | 1..4 light (S = 8,16,32,64) | 5..7 mid (T = 1024,4096,8192) | 8 heavy
-constexpr uint32_t MID_MAX = 4096;
+#ifndef MID_MAX_V
+#define MID_MAX_V 4096
+#endif
+constexpr uint32_t MID_MAX = MID_MAX_V;
 #ifndef DENSE_U
 #define DENSE_U 1
 #endif
@@ -1621,8 +1624,8 @@ template <int MODE>
 static void launch_mid(spsamd_ctx *c, const Bins &b, const MidCells &mc, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
 	launch_hash<1024, 256, MODE, false>(c, mc.cells[0], b.count[5], nullptr, m, nullptr, 0, ep, sk);
-	launch_hash<4096, 256, MODE, false>(c, mc.cells[1], b.count[6], nullptr, m, nullptr, 0, ep, sk);
-	launch_hash<8192, 256, MODE, false>(c, mc.cells[2], b.count[7], nullptr, m, nullptr, 0, ep, sk);
+	launch_hash<4096, 512, MODE, false>(c, mc.cells[1], b.count[6], nullptr, m, nullptr, 0, ep, sk);
+	launch_hash<8192, 512, MODE, false>(c, mc.cells[2], b.count[7], nullptr, m, nullptr, 0, ep, sk);   // 115 KB of LDS: one workgroup per CU, so make it 8 waves
 }
 
 struct Heavy {
