@@ -3,7 +3,7 @@
 ~16M tuples) on N MI355X GPUs of one node, plus the dominant kernel's roofline
 line and (N=1) the CPU port of the reference algorithm beside it.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W          (--workload poisson --grid 4096: cfg3 instead of cfg2)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", type=int, default=20, help="R-MAT scale (cfg2 = 20, cfg4 = 23)")
+    ap.add_argument("--workload", choices=["rmat", "poisson"], default="rmat",
+                    help="rmat: cfg2/cfg4 (the benchmarked line); poisson: cfg3, the 2-D 5-point stencil on a --grid x --grid mesh")
+    ap.add_argument("--grid", type=int, default=4096, help="mesh size of --workload poisson (cfg3 = 4096)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
@@ -137,13 +140,22 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = capi.Context(local_rank, stream.cuda_stream)
     scale, seed = args.scale, args.seed
-    n, ne = 1 << scale, 16 << scale
+    if args.workload == "poisson":
+        n, ne = args.grid * args.grid, 5 * args.grid * args.grid - 4 * args.grid
+        wname = "2-D 5-point Poisson stencil on a %dx%d mesh, A*A, fp64, COO tuples resident in HBM, digest sink" % (args.grid, args.grid)
+    else:
+        n, ne = 1 << scale, 16 << scale
+        wname = ("R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
+                 "raw COO tuples resident in HBM, digest sink" % (scale, seed))
 
     def gen_all():
         t0 = torch.empty(ne, dtype=torch.int32, device=dev)
         t1 = torch.empty(ne, dtype=torch.int32, device=dev)
         tv = torch.empty(ne, dtype=torch.float64, device=dev)
-        ctx.gen_rmat(scale, seed, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+        if args.workload == "poisson":
+            ctx.gen_poisson2d(args.grid, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+        else:
+            ctx.gen_rmat(scale, seed, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
         return t0, t1, tv
 
     def consolidated(coo):
@@ -280,7 +292,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if scale == 20 and world == 1 and name in pmc["kernels"]:
+            if args.workload == "rmat" and scale == 20 and world == 1 and name in pmc["kernels"]:
                 traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
@@ -298,8 +310,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
-                            "raw COO tuples resident in HBM, digest sink" % (scale, seed),
+                "workload": wname,
                 "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
                 "parallelism": "1 GPU" if world == 1 else "%d row blocks (per-row cost estimate, then %d measure/rebalance rounds) + all-to-allv of B row panels" % (world, len(calib)),
                 "remote_panel_tuples": remote_total,

@@ -312,7 +312,8 @@ def test_bench_dist_path_matches_plain_path():
         assert d["unit"] == "nnz(C)/s" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("wl_args", [["--scale", "16"], ["--workload", "poisson", "--grid", "512"]], ids=["rmat16", "poisson512"])
+def test_bench_two_ranks_on_one_gpu(wl_args):
     """The multi-rank control flow of bench.py with REAL second rank: two processes (torch.distributed.run),
     both on cuda:0, collectives over gloo on host copies (--rehearse-gloo).  Distinct row blocks per rank,
     calibration + rebalancing, panel exchange between different owners, digest reduction: the whole-job
@@ -322,7 +323,7 @@ def test_bench_two_ranks_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    base = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--scale", "16"]
+    base = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + wl_args       # R-MAT: whole-block panels; stencil: exact panels
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + base, cwd=root, env=env,
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-2000:]
