@@ -289,6 +289,30 @@ def test_fuzz_shapes_flags_and_sinks(ctx):
     assert seen["light"] >= 5 and seen["mid"] >= 5 and seen["heavy"] >= 5 and seen["hash_cells"] >= 3 and seen["dense_cells"] >= 3
 
 
+def test_fuzz_nan_values_and_zero_nan(ctx):
+    """NaN operand values with zero_nan on and off (consolidate's literal behaviour: a NaN is dropped only
+    where it leads a run of equal indices, algorithm.hpp:272-275 vs :284-292; surviving NaNs poison their
+    sums).  Index sets identical; values identical including the NaN positions (ordered mode)."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        m, k, n = [(6, 9, 7), (40, 300, 9000), (3, 2500, 12000), (120, 50, 60)][case % 4]
+        A = _rand_mat(rng, (m, k), max(1, int(m * k * 0.3)), zeros=True)
+        B = _rand_mat(rng, (k, n), max(1, min(int(k * n * 0.05), 200000)), zeros=bool(case % 2))
+        for M in (A, B):
+            M.val[rng.integers(0, M.val.size, max(1, M.val.size // 50))] = np.nan
+        kw = dict(zero_nan=bool(case % 3), duplicate_policy=int(rng.choice([capi.ADD, capi.LEAVE_ALONE, capi.REPLACE])))
+        want = orc.multiply(A, B, rowwise=True, nthreads=8, **kw)
+        got = _dev(ctx, A, B, flags=capi.SINK_ORDERED, **kw)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.array_equal(got[2], want[2], equal_nan=True)
+        g2 = _dev(ctx, A, B, **kw)                              # arrival-order sums: NaN stays NaN, the rest to rounding
+        assert np.array_equal(g2[0], want[0]) and np.array_equal(g2[1], want[1])
+        assert np.array_equal(np.isnan(g2[2]), np.isnan(want[2]))
+        ok = ~np.isnan(want[2])
+        assert np.allclose(g2[2][ok], want[2][ok], rtol=1e-12, atol=0)
+
+
 def test_bench_dist_path_matches_plain_path():
     """bench.py's N>1 code (row block, calibration rounds, all-to-allv of B panels over RCCL, digest
     reduction) rehearsed on a 1-rank NCCL group: same digest as the plain single-GPU path."""
