@@ -235,25 +235,39 @@ __global__ __launch_bounds__(RS_NT) void k_rs_hist(const uint64_t *keys, size_t 
 
 // Stable scatter: wave w of a workgroup owns the contiguous items
 // [tile + w*1024, tile + (w+1)*1024) and walks them 64 at a time, so the order
-// (workgroup, wave, chunk, lane) is the input order.
+// (workgroup, wave, chunk, lane) is the input order.  The tile is first sorted by digit INSIDE the
+// workgroup (LDS), then written out: a digit's items leave as one contiguous run instead of one
+// 12-byte record per lane (the direct scatter ran at 1.2 TB/s of record traffic).
 __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const uint64_t *keys, const uint32_t *pay, size_t n, int shift,
 	const uint32_t *gbase, unsigned nblocks, uint64_t *keys_out, uint32_t *pay_out, int iota_payload)
 {
 	__shared__ uint32_t wcnt[RS_NW][256];
+	__shared__ uint32_t gdelta[256];               // global position of a digit's run minus its position in the tile
+	__shared__ uint32_t scr[RS_NW + 1];
+	__shared__ uint64_t s_key[RS_TILE];
+	__shared__ uint32_t s_pay[RS_TILE];
 	const unsigned w = wave_id(), lane = lane_id();
 	for (int q = threadIdx.x; q < RS_NW * 256; q += RS_NT) (&wcnt[0][0])[q] = 0;
 	__syncthreads();
-	const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (RS_ITER * 64);
-#pragma unroll 4
+	const size_t tile = (size_t)blockIdx.x * RS_TILE;
+	const size_t wbase = tile + (size_t)w * (RS_ITER * 64);
+	uint64_t key[RS_ITER];
+#pragma unroll
 	for (int q = 0; q < RS_ITER; ++q) {
 		size_t i = wbase + (size_t)q * 64 + lane;
-		if (i < n) atomicAdd(&wcnt[w][(unsigned)(keys[i] >> shift) & 255u], 1u);
+		key[q] = i < n ? keys[i] : 0;
+		if (i < n) atomicAdd(&wcnt[w][(unsigned)(key[q] >> shift) & 255u], 1u);
 	}
 	__syncthreads();
 	{
-		// thread d turns the per-wave counts of digit d into per-wave output bases
+		// thread d: digit d's run inside the tile (exclusive prefix over the digits) and per-wave starts in it
 		unsigned d = threadIdx.x;
-		uint32_t run = gbase[(size_t)d * nblocks + blockIdx.x];
+		uint32_t tot = 0;
+#pragma unroll
+		for (int ww = 0; ww < RS_NW; ++ww) tot += wcnt[ww][d];
+		uint32_t lbase = block_exclusive_scan<uint32_t, RS_NT>(tot, scr, (uint32_t *)nullptr);
+		gdelta[d] = gbase[(size_t)d * nblocks + blockIdx.x] - lbase;
+		uint32_t run = lbase;
 #pragma unroll
 		for (int ww = 0; ww < RS_NW; ++ww) {
 			uint32_t t = wcnt[ww][d];
@@ -262,11 +276,11 @@ __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const uint64_t *keys, cons
 		}
 	}
 	__syncthreads();
+#pragma unroll
 	for (int q = 0; q < RS_ITER; ++q) {
 		size_t i = wbase + (size_t)q * 64 + lane;
 		bool valid = i < n;
-		uint64_t key = valid ? keys[i] : 0;
-		unsigned digit = (unsigned)(key >> shift) & 255u;
+		unsigned digit = (unsigned)(key[q] >> shift) & 255u;
 		uint64_t peers = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; ++b) {
@@ -281,10 +295,17 @@ __global__ __launch_bounds__(RS_NT) void k_rs_scatter(const uint64_t *keys, cons
 		int leader = valid ? (__ffsll((unsigned long long)peers) - 1) : (int)lane;
 		old = __shfl(old, leader, 64);
 		if (valid) {
-			uint32_t dst = old + rank;
-			keys_out[dst] = key;
-			pay_out[dst] = iota_payload ? (uint32_t)i : pay[i];
+			s_key[old + rank] = key[q];
+			s_pay[old + rank] = iota_payload ? (uint32_t)i : pay[i];
 		}
+	}
+	__syncthreads();
+	const uint32_t nvalid = (uint32_t)(n - tile < (size_t)RS_TILE ? n - tile : (size_t)RS_TILE);
+	for (uint32_t p = threadIdx.x; p < nvalid; p += RS_NT) {
+		const uint64_t k = s_key[p];
+		const uint32_t dst = gdelta[(unsigned)(k >> shift) & 255u] + p;
+		keys_out[dst] = k;
+		pay_out[dst] = s_pay[p];
 	}
 }
 
