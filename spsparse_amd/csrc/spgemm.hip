@@ -1182,18 +1182,17 @@ __global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwi
 
 // Per heavy row: products per column window.  One workgroup per row; a thread owns a PAIR of
 // windows (one 32-bit load per A tuple), sub-groups of threads take different tuples and every
-// thread keeps 8 tuples in flight: the longest hub row (tens of thousands of tuples, one
-// workgroup) sets this kernel's time.
+// thread keeps 8 tuples in flight.  A row's workgroup takes at most WH_HUB tuples; rows with more
+// are noted in a list and their remaining tuples are dealt in parts to a second launch that adds
+// into the row's histogram with global atomics (the longest hub row -- tens of thousands of tuples
+// -- would otherwise set the time of the whole kernel).
 constexpr int WH_NT = 256;
 constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
-__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
-	uint32_t nwin, uint32_t nwp, uint32_t *winprod)
+constexpr uint32_t WH_HUB = 4096;            // tuples one workgroup takes
+constexpr uint32_t WH_HUB_MAX = 65536;       // list capacity (rows beyond it are finished by their own workgroup)
+
+__device__ __forceinline__ void win_hist_span(const RowMeta &m, const uint16_t *wcnt, uint32_t nwp, uint32_t beg, uint32_t end, uint32_t *s_cnt)
 {
-	__shared__ uint32_t s_cnt[WH_MAXW];
-	const uint32_t h = blockIdx.x, r = hrows[h];
-	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
-	for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
-	__syncthreads();
 	const uint32_t npair = nwp >> 1;
 	const uint32_t *tab = (const uint32_t *)wcnt;                       // row k: npair words
 	uint32_t ppad = 1;
@@ -1211,11 +1210,55 @@ __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint3
 			for (int u = 0; u < 8; ++u) { c0 += x[u] & 0xFFFFu; c1 += x[u] >> 16; }
 		}
 		for (; e < end; e += nsub) { const uint32_t x = tab[(uint64_t)m.acol[e] * npair + p]; c0 += x & 0xFFFFu; c1 += x >> 16; }
-		if (nsub > 1) { if (c0) atomicAdd(&s_cnt[2 * p], c0); if (c1) atomicAdd(&s_cnt[2 * p + 1], c1); }
-		else { s_cnt[2 * p] = c0; s_cnt[2 * p + 1] = c1; }
+		if (c0) atomicAdd(&s_cnt[2 * p], c0);
+		if (c1) atomicAdd(&s_cnt[2 * p + 1], c1);
+	}
+}
+
+__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, uint32_t *hubcount, uint32_t *hublist)
+{
+	__shared__ uint32_t s_cnt[WH_MAXW];
+	__shared__ uint32_t s_listed;
+	const uint32_t h = blockIdx.x, r = hrows[h];
+	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
+	for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
+	if (threadIdx.x == 0) {
+		uint32_t listed = 0;
+		if (end - beg > WH_HUB) {
+			const uint32_t slot = atomicAdd(hubcount, 1u);
+			if (slot < WH_HUB_MAX) { hublist[slot] = h; listed = 1; }
+		}
+		s_listed = listed;
 	}
 	__syncthreads();
+	win_hist_span(m, wcnt, nwp, beg, s_listed ? beg + WH_HUB : end, s_cnt);
+	__syncthreads();
 	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
+}
+
+// The tuples beyond WH_HUB of the listed rows, WH_HUB at a time: work item = (listed row, part).
+__global__ __launch_bounds__(WH_NT) void k_win_hist_hub(const uint32_t *hrows, RowMeta m, const uint16_t *wcnt,
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, const uint32_t *hubcount, const uint32_t *hublist)
+{
+	__shared__ uint32_t s_cnt[WH_MAXW];
+	const uint32_t nhub = min(*hubcount, WH_HUB_MAX);
+	// items are enumerated row by row; a workgroup finds its items by walking the (short) list
+	uint32_t item = 0;
+	for (uint32_t q = 0; q < nhub; ++q) {
+		const uint32_t h = hublist[q], r = hrows[h];
+		const uint32_t beg = m.beg[r] + WH_HUB, end = m.beg[r + 1];
+		const uint32_t parts = (end - beg + WH_HUB - 1) / WH_HUB;
+		for (uint32_t part = 0; part < parts; ++part, ++item) {
+			if (item % gridDim.x != blockIdx.x) continue;                 // uniform
+			for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
+			__syncthreads();
+			win_hist_span(m, wcnt, nwp, beg + part * WH_HUB, min(end, beg + (part + 1) * WH_HUB), s_cnt);
+			__syncthreads();
+			for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) { const uint32_t v = s_cnt[w]; if (v) atomicAdd(&winprod[(uint64_t)h * nwin + w], v); }
+			__syncthreads();
+		}
+	}
 }
 
 // Cell classes: 0..3 hash (T = 1024 / 3072 / 4096 / 8192 slots; T/2 products), 4 dense
@@ -1712,7 +1755,12 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * nwp);
 	k_bwin_counts<<<dim3(4096), dim3(256), 0, st>>>(hv.bwin, nrowb, hv.nwin, nwp, wcnt);
 	SPS_LAUNCH_CHECK();
-	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod);
+	uint32_t *hubcount = c->arena.get<uint32_t>(1);
+	uint32_t *hublist = c->arena.get<uint32_t>(WH_HUB_MAX);
+	fill_zero(c, hubcount, sizeof(uint32_t));
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
+	SPS_LAUNCH_CHECK();
+	k_win_hist_hub<<<dim3((unsigned)c->num_cu * 4u), dim3(WH_NT), 0, st>>>(hv.rows, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) {
 		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
