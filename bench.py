@@ -229,7 +229,7 @@ def main():
             dist.all_gather(every, mine)
             times = [float(x[0]) for x in every]
             calib.append([round(x, 2) for x in times])
-            bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times, min_gain=0.03)
+            bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times, min_gain=0.015)
             del blk
         bounds = bounds_now[0]
         block = take_block(bounds)

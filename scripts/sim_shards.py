@@ -52,7 +52,7 @@ def main():
             print("world %d (%s) round %d: block ms %s | max %.1f -> speed-up %.2fx (compute only) | products %s" % (
                 world, mode, rnd, " ".join("%.1f" % t for t in times), max(times), full.ms_total / max(times),
                 " ".join("%.2g" % p for p in prods)), flush=True)
-            bounds = sd.rebalance_bounds(bounds, cost_prefix, times, min_gain=0.03)
+            bounds = sd.rebalance_bounds(bounds, cost_prefix, times, min_gain=0.015)
 
 
 def fixed_cost():
