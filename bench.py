@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
-    ap.add_argument("--calibrate", type=int, default=2,
+    ap.add_argument("--calibrate", type=int, default=3,
                     help="N>1 setup: measure/rebalance rounds of the row-block boundaries (0: cost estimate only)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on ONE GPU: every rank uses cuda:0, collectives run over gloo on host copies "
