@@ -1330,8 +1330,16 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		}
 		++n[cls]; np[cls] += cur; ++ordinal; cur = 0;
 	};
+	// the row's histogram is read four windows per load where the row is 16-byte aligned (one thread per
+	// row: consecutive threads are a whole row apart, so narrow loads waste most of every cache line)
+	const bool vec4 = (nwin & 3u) == 0;
+	uint4 quad = make_uint4(0, 0, 0, 0);
 	for (uint32_t w = 0; w < nwin; ++w) {
-		uint32_t c = wp[w];
+		uint32_t c;
+		if (vec4) {
+			if ((w & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(wp + w);
+			c = (w & 3u) == 0 ? quad.x : ((w & 3u) == 1 ? quad.y : ((w & 3u) == 2 ? quad.z : quad.w));
+		} else c = wp[w];
 		if (c > dense_min) {
 			flush();
 			if (WRITE) {
