@@ -144,6 +144,19 @@ public:
 		val_vec.push_back(val);
 	}
 
+	// Bulk form of add() for tuples the library produced: same edit-mode rule, same bounds rule (checked
+	// on the whole chunk), one append per column instead of one push_back per tuple and column.  multiply()
+	// uses it when the sink is this container; any other Accumulator still receives one add() per tuple.
+	void add_tuples(const IndexT *const *index, const ValT *val, size_t n)
+	{
+		if (!edit_mode) (*spsparse_error)(-1, "Must be in edit mode to use VectorCooArray::add()");
+		for (int k = 0; k < RANK; ++k)
+			for (size_t q = 0; q < n; ++q)
+				if (index[k][q] < 0 || (size_t)index[k][q] >= shape[k]) { add_one_of(index, val, q); return; }   // raises like add()
+		for (int k = 0; k < RANK; ++k) index_vecs[k].insert(index_vecs[k].end(), index[k], index[k] + n);
+		val_vec.insert(val_vec.end(), val, val + n);
+	}
+
 	// VectorCooArray.hpp:143-147: the index columns are permuted in place; like the reference's
 	// OverwriteAccum it leaves shape and sort_order as they were.
 	void transpose(std::array<int, RANK> const &perm)
@@ -159,6 +172,13 @@ public:
 protected:
 	std::array<std::vector<IndexT>, RANK> index_vecs;
 	std::vector<ValT> val_vec;
+
+	void add_one_of(const IndexT *const *index, const ValT *val, size_t q)
+	{
+		std::array<IndexT, RANK> ix;
+		for (int k = 0; k < RANK; ++k) ix[k] = index[k][q];
+		add(ix, val[q]);
+	}
 };
 
 // ---- the accumulators of accum.hpp that make sense around multiply(), host side -------------
@@ -277,7 +297,12 @@ template <class AccumulatorT>
 int add_chunk(void *user, const int32_t *i, const int32_t *j, const double *v, size_t n)
 {
 	AccumulatorT &ret = *static_cast<AccumulatorT *>(user);
-	for (size_t q = 0; q < n; ++q) ret.add({i[q], j[q]}, v[q]);      // multiply_sparse.hpp:242
+	if constexpr (std::is_same<AccumulatorT, VectorCooArray<int32_t, double, 2>>::value) {
+		const int32_t *cols[2] = {i, j};
+		ret.add_tuples(cols, v, n);                                  // same tuples, same order, appended in bulk
+	} else {
+		for (size_t q = 0; q < n; ++q) ret.add({i[q], j[q]}, v[q]);  // multiply_sparse.hpp:242
+	}
 	return 0;
 }
 
