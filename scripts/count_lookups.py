@@ -55,3 +55,16 @@ Lh = L[heavy]
 print("cells", int(ncell.sum()), "dense", int(ndense.sum()), "lookups sum(ncell*L)", int((ncell * Lh).sum()),
       "dense-cell lookups", int((ndense * Lh).sum()))
 print("products per lookup", int(P[heavy].sum()) / int((ncell * Lh).sum()))
+
+# how many of the (cell, A tuple) lookups find a non-empty B segment
+ne_kw = (cnt_kw > 0).to(torch.float32)
+ne = torch.zeros(nh, nwin, dtype=torch.float32, device=dev)
+for s in range(0, a_r.numel(), CH):
+    ne.index_add_(0, a_r[s:s + CH], ne_kw[a_k[s:s + CH]])
+dense_mask = wp > 2048
+print("dense cells: lookups %.4g, of them non-empty %.4g (%.1f%%)" % (
+    float((dense_mask.float() * Lh[:, None].float()).sum()), float((ne * dense_mask.float()).sum()),
+    100.0 * float((ne * dense_mask.float()).sum()) / float((dense_mask.float() * Lh[:, None].float()).sum())))
+hash_mask = (wp > 0) & ~dense_mask
+print("hash windows: (row, window) pairs with products %.4g, non-empty segments in them %.4g, lookups if one per window %.4g" % (
+    float(hash_mask.sum()), float((ne * hash_mask.float()).sum()), float((hash_mask.float() * Lh[:, None].float()).sum())))
