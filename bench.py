@@ -3,13 +3,19 @@
 ~16M tuples) on N MI355X GPUs of one node, plus the dominant kernel's roofline
 line and (N=1) the CPU port of the reference algorithm beside it.
 
-    python bench.py --gpus 1 --steps K --warmup W          (--workload poisson --grid 4096: cfg3 instead of cfg2)
+    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --workload poisson|galerkin|rmat [--scale S] [--grid G]     (one other config as the headline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path over the whole synthetic matrix:
   N = 1   spsamd_multiply(A, A) from the raw, device-resident COO tuples
           (device consolidate + symbolic + numeric) into the digest sink.
+          The JSON line's `other_configs` object carries, measured in the same
+          run (fewer steps each): cfg3 (Poisson 4096^2, digest and COO sinks),
+          cfg5 (Galerkin R*A*R^T on 256^3, two chained COO multiplies), cfg4 on
+          one GPU (R-MAT scale-23) and cfg2 into the COO sink with the
+          PCIe-inclusive host delivery rate.  --no-other-configs skips them.
   N > 1   strong scaling on the same matrix: every rank owns a contiguous row
           block of the raw tuples; a step = consolidate the own block,
           all-to-allv of the needed B row panels (RCCL), multiply the block
@@ -20,8 +26,9 @@ One step = one pass of the hot path over the whole synthetic matrix:
           before the warmup and timed steps.
 The digest sink (count + value sum + index hash of the emitted tuples) is the
 device analogue of the reference's ScalarAccumulator (accum.hpp:158-167):
-nnz(C) ~ 9.7e9 tuples (155 GB) is never materialised.  Inputs are generated
-in HBM before the timed region; nothing crosses PCIe inside it.
+nnz(C) ~ 9.7e9 tuples (155 GB) is never materialised in the headline run.
+Inputs are generated in HBM before the timed region; nothing crosses PCIe
+inside it.
 """
 import argparse
 import json
@@ -34,6 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
 
 
 def parse():
@@ -42,11 +50,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", type=int, default=20, help="R-MAT scale (cfg2 = 20, cfg4 = 23)")
-    ap.add_argument("--workload", choices=["rmat", "poisson"], default="rmat",
-                    help="rmat: cfg2/cfg4 (the benchmarked line); poisson: cfg3, the 2-D 5-point stencil on a --grid x --grid mesh")
-    ap.add_argument("--grid", type=int, default=4096, help="mesh size of --workload poisson (cfg3 = 4096)")
+    ap.add_argument("--workload", choices=["rmat", "poisson", "galerkin"], default="rmat",
+                    help="rmat: cfg2/cfg4 (the benchmarked line); poisson: cfg3, the 2-D 5-point stencil on a --grid x --grid "
+                         "mesh; galerkin: cfg5, R*A*R^T on the 7-point Laplacian of a --grid^3 mesh (default 256)")
+    ap.add_argument("--grid", type=int, default=0, help="mesh size of --workload poisson (cfg3 = 4096) / galerkin (cfg5 = 256)")
+    ap.add_argument("--sink", choices=["digest", "coo"], default="digest", help="N=1: the sink of the timed multiply")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N=1: only the headline workload")
     ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
     ap.add_argument("--calibrate", type=int, default=3,
                     help="N>1 setup: measure/rebalance rounds of the row-block boundaries (0: cost estimate only)")
@@ -65,6 +76,7 @@ def cpu_baseline(scale, seed):
     the same workload.  Reported beside the GPU number, never the target.
     Also timed: the same port on cfg1, and the row-wise
     checker at one thread and at every host core."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")      # idle OpenMP workers sleep instead of spinning until exit
     from oracle import binding as orc
     from spsparse_amd import workloads as wl
     A = orc.Mat(*wl.rmat(scale, seed))
@@ -99,6 +111,123 @@ def cpu_baseline(scale, seed):
             "rowwise_port_value": len(v) / dt2,
             "rowwise_port_all_cores_value": len(v) / dt3, "host_cores": ncores, "cpu_model": model,
             "cfg1_value": len(c1[2]) / dt1, "cfg1_sample": "1k x 1k, 10 tuples per row, A*B: nnz(C)=%d in %.3f s" % (len(c1[2]), dt1)}
+
+
+# ------------------------------------------------------------------------------------------ N = 1 workloads
+
+class Workload:
+    """Device-resident operands of one BASELINE config and its step."""
+
+    def __init__(self, torch, capi, ctx, dev, kind, scale=20, grid=0, seed=1, sink="digest"):
+        self.torch, self.capi, self.ctx, self.kind = torch, capi, ctx, kind
+        self.sink = capi.SINK_COO if sink == "coo" else capi.SINK_DIGEST
+        self.sink_name = sink
+
+        def bufs(m):
+            return (torch.empty(m, dtype=torch.int32, device=dev), torch.empty(m, dtype=torch.int32, device=dev),
+                    torch.empty(m, dtype=torch.float64, device=dev))
+
+        def ptrs(t):
+            return [x.data_ptr() for x in t]
+
+        if kind == "rmat":
+            self.n, self.ne = 1 << scale, 16 << scale
+            self.t = bufs(self.ne)
+            ctx.gen_rmat(scale, seed, 0, self.ne, *ptrs(self.t))
+            self.A = capi.device_coo(*ptrs(self.t), self.ne, (self.n, self.n))
+            self.name = ("R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
+                         "raw COO tuples resident in HBM, %s sink" % (scale, seed, sink))
+            self.workspace = int(self.ne * 220) + (512 << 20)
+        elif kind == "poisson":
+            g = grid or 4096
+            self.n, self.ne = g * g, 5 * g * g - 4 * g
+            self.t = bufs(self.ne)
+            ctx.gen_poisson2d(g, *ptrs(self.t))
+            self.A = capi.device_coo(*ptrs(self.t), self.ne, (self.n, self.n))
+            self.name = "2-D 5-point Poisson stencil on a %dx%d mesh, A*A, fp64, COO tuples resident in HBM, %s sink" % (g, g, sink)
+            self.workspace = int(self.ne * 220) + (512 << 20)
+        else:
+            g = grid or 256
+            nc = g // 2
+            self.n = nc ** 3
+            na = 7 * g ** 3 - 6 * g ** 2
+            self.ne = na + g ** 3
+            self.t = bufs(na)
+            self.t2 = bufs(g ** 3)
+            ctx.gen_laplace3d(g, *ptrs(self.t))
+            ctx.gen_aggregation3d(g, *ptrs(self.t2))
+            self.A = capi.device_coo(*ptrs(self.t), na, (g ** 3, g ** 3), sort0=0)
+            self.R = capi.device_coo(*ptrs(self.t2), g ** 3, (nc ** 3, g ** 3), sort0=0)
+            self.sink, self.sink_name = capi.SINK_COO, "coo"
+            self.name = ("Galerkin triple product R*A*R^T, 7-point Laplacian on a %d^3 mesh, 2x2x2 aggregation, fp64: T = R*A into "
+                         "the COO sink, C = T*R^T reading T in place (chained result buffers), COO sink" % g)
+            self.workspace = int(na * 260) + (512 << 20)
+        torch.cuda.synchronize()
+
+    def step(self):
+        """One pass; returns the list of spsamd_result of its multiplies (one, or two for galerkin)."""
+        capi, ctx = self.capi, self.ctx
+        if self.kind == "galerkin":
+            rt = ctx.multiply(self.R, self.A, sink=capi.SINK_COO)
+            rc = ctx.multiply(capi.result_operand(rt), self.R, tB="T", sink=capi.SINK_COO)
+            return [rt, rc]
+        return [ctx.multiply(self.A, self.A, sink=self.sink)]
+
+    def release(self):
+        self.t = self.t2 = None
+        self.torch.cuda.empty_cache()
+
+
+def run_workload(torch, w, steps, warmup):
+    """warmup + timed steps of one workload on one GPU; returns the summary dict and the per-step results."""
+    w.ctx.reserve(w.workspace)
+    for _ in range(warmup):
+        w.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = [w.step() for _ in range(steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    last = results[-1]
+    ms_step = elapsed / steps * 1e3
+    nnz_c = int(last[-1].nnz)
+    read_alg = sum(16 * int(r.nnz_a) + 12 * int(r.products) for r in last)
+    write_alg = sum(16 * int(r.nnz) for r in last) if w.sink_name == "coo" else 0
+    out = {
+        "workload": w.name, "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
+        "nnz_c_per_s": nnz_c / (ms_step * 1e-3),
+        "n": w.n, "raw_tuples": w.ne,
+        "nnz_a": [int(r.nnz_a) for r in last], "nnz_b": [int(r.nnz_b) for r in last],
+        "products": [int(r.products) for r in last], "nnz_c": [int(r.nnz) for r in last],
+        "read_alg_bytes": read_alg, "read_alg_GBps": read_alg / (ms_step * 1e-3) / 1e9,
+        "read_alg_frac_of_hbm_peak": read_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "read_write_alg_GBps": (read_alg + write_alg) / (ms_step * 1e-3) / 1e9,
+        "stage_ms": [{"consolidate": r.ms_consolidate, "symbolic": r.ms_symbolic, "numeric": r.ms_numeric, "light": r.ms_light,
+                      "mid": r.ms_mid, "heavy_hash_cells": r.ms_heavy - r.ms_dense, "heavy_dense_cells": r.ms_dense,
+                      "total_device": r.ms_total} for r in last],
+        "window": int(last[0].window), "workspace_GB": max(int(r.workspace_bytes) for r in last) / 1e9,
+    }
+    if w.sink_name == "digest":
+        out["digest"] = {"sum": float(last[0].sum), "hash": "%016x" % int(last[0].hash)}
+    return out, results
+
+
+def pcie_delivery(torch, capi, ctx, dev, scale, seed):
+    """PCIe-inclusive host delivery of a COO result (never `value`): R-MAT scale-`scale` A*A, host COO in ->
+    spsamd_multiply -> spsamd_result_fetch into host arrays; nnz(C)/s end to end."""
+    import numpy as np
+    from spsparse_amd import workloads as wl
+    a = wl.rmat(scale, seed)
+    s, keep = capi.host_coo(*a)
+    ctx.multiply(s, s, sink=capi.SINK_COO)           # warm: workspace, output buffers
+    t0 = time.perf_counter()
+    res = ctx.multiply(s, s, sink=capi.SINK_COO)
+    t1 = time.perf_counter()
+    gi, gj, gv = ctx.fetch(res)
+    t2 = time.perf_counter()
+    return {"sample": "R-MAT scale-%d A*A, host operands, COO sink fetched into host arrays" % scale, "nnz_c": int(res.nnz),
+            "multiply_with_h2d_ms": (t1 - t0) * 1e3, "fetch_ms": (t2 - t1) * 1e3,
+            "fetch_GBps": int(res.nnz) * 16 / (t2 - t1) / 1e9, "end_to_end_nnz_c_per_s": int(res.nnz) / (t2 - t0)}
 
 
 def main():
@@ -140,9 +269,20 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = capi.Context(local_rank, stream.cuda_stream)
     scale, seed = args.scale, args.seed
+
+    if not use_dist:
+        line = single_gpu(args, torch, capi, ctx, dev, stream)
+        print(json.dumps(line), flush=True)
+        ctx.close()
+        finish()
+        return
+
+    if args.workload == "galerkin":
+        raise SystemExit("--workload galerkin is a single-GPU line here (its 2-GPU split is covered by tests/test_dist_gloo.py)")
     if args.workload == "poisson":
-        n, ne = args.grid * args.grid, 5 * args.grid * args.grid - 4 * args.grid
-        wname = "2-D 5-point Poisson stencil on a %dx%d mesh, A*A, fp64, COO tuples resident in HBM, digest sink" % (args.grid, args.grid)
+        g = args.grid or 4096
+        n, ne = g * g, 5 * g * g - 4 * g
+        wname = "2-D 5-point Poisson stencil on a %dx%d mesh, A*A, fp64, COO tuples resident in HBM, digest sink" % (g, g)
     else:
         n, ne = 1 << scale, 16 << scale
         wname = ("R-MAT scale-%d A*A (Graph500 a,b,c,d=0.57,0.19,0.19,0.05, edge factor 16, seed %d), fp64, "
@@ -153,7 +293,7 @@ def main():
         t1 = torch.empty(ne, dtype=torch.int32, device=dev)
         tv = torch.empty(ne, dtype=torch.float64, device=dev)
         if args.workload == "poisson":
-            ctx.gen_poisson2d(args.grid, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
+            ctx.gen_poisson2d(args.grid or 4096, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
         else:
             ctx.gen_rmat(scale, seed, 0, ne, t0.data_ptr(), t1.data_ptr(), tv.data_ptr())
         return t0, t1, tv
@@ -175,74 +315,67 @@ def main():
     # setup: pre-size the library's workspace (about 170 B per raw tuple at these sizes) so that
     # no timed step -- not even the first one when --warmup 0 -- allocates device memory
     ctx.reserve(int(ne * 220) + (512 << 20))
-    if not use_dist:
-        A = capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n))
+    # setup (untimed): contiguous row blocks equal in estimated time, identical on every rank ...
+    c0, c1, cv = consolidated(capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n)))
+    rowlen = torch.bincount(c0.long(), minlength=n)
+    P = sd.row_products(c0, c1, rowlen, n)
+    cost = sd.row_cost(P)
+    cost_prefix = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cost, 0)])
+    bounds = sd.product_balanced_bounds(cost, world)
+    del c0, c1, cv, P, rowlen, cost
 
-        def step():
-            return ctx.multiply(A, A, sink=capi.SINK_DIGEST), 0
-    else:
-        # setup (untimed): contiguous row blocks equal in estimated time, identical on every rank ...
-        c0, c1, cv = consolidated(capi.device_coo(raw0.data_ptr(), raw1.data_ptr(), rawv.data_ptr(), ne, (n, n)))
-        rowlen = torch.bincount(c0.long(), minlength=n)
-        P = sd.row_products(c0, c1, rowlen, n)
-        cost = sd.row_cost(P)
-        cost_prefix = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cost, 0)])
-        bounds = sd.product_balanced_bounds(cost, world)
-        del c0, c1, cv, P, rowlen, cost
+    def take_block(b):
+        keep = (raw0 >= b[rank]) & (raw0 < b[rank + 1])
+        return raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
 
-        def take_block(b):
-            keep = (raw0 >= b[rank]) & (raw0 < b[rank + 1])
-            return raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
+    def run_block(blk):
+        """One step on this rank's block; also returns the time of its local part (consolidate +
+        multiply, without the exchange, where a rank also waits for the slowest one)."""
+        blk0, blk1, blkv = blk
+        t_a = time.perf_counter()
+        a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n)))
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        if args.rehearse_gloo:
+            h0, h1, hv = a0.cpu(), a1.cpu(), av.cpu()
+            p0, p1, pv, remote = sd.exchange_b_panels(h1, h0, h1, hv, bounds_now[0], n)
+            p0, p1, pv = p0.to(dev), p1.to(dev), pv.to(dev)
+        else:
+            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
+        Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
+        Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        res = ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST)
+        t_d = time.perf_counter()
+        return res, remote, ((t_b - t_a) + (t_d - t_c)) * 1e3
 
-        def run_block(blk):
-            """One step on this rank's block; also returns the time of its local part (consolidate +
-            multiply, without the exchange, where a rank also waits for the slowest one)."""
-            blk0, blk1, blkv = blk
-            t_a = time.perf_counter()
-            a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n)))
-            torch.cuda.synchronize()
-            t_b = time.perf_counter()
-            if args.rehearse_gloo:
-                h0, h1, hv = a0.cpu(), a1.cpu(), av.cpu()
-                p0, p1, pv, remote = sd.exchange_b_panels(h1, h0, h1, hv, bounds_now[0], n)
-                p0, p1, pv = p0.to(dev), p1.to(dev), pv.to(dev)
-            else:
-                p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
-            Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
-            Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
-            torch.cuda.synchronize()
-            t_c = time.perf_counter()
-            res = ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST)
-            t_d = time.perf_counter()
-            return res, remote, ((t_b - t_a) + (t_d - t_c)) * 1e3
+    # ... then corrected by measurement: run the step, gather every rank's local time, move the
+    # boundaries so that the measured times come out equal (sd.rebalance_bounds), repeat.
+    bounds_now = [bounds]
+    calib = []
+    for _ in range(max(0, args.calibrate)):
+        blk = take_block(bounds_now[0])
+        run_block(blk)
+        local_ms = min(run_block(blk)[2] for _ in range(3))        # best of three: the timer noise is about 1 ms
+        mine = torch.tensor([local_ms], dtype=torch.float64, device=coll_dev)
+        every = [torch.empty(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        times = [float(x[0]) for x in every]
+        calib.append([round(x, 2) for x in times])
+        bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times, min_gain=0.015)
+        del blk
+    bounds = bounds_now[0]
+    block = take_block(bounds)
+    del raw0, raw1, rawv, cost_prefix
+    torch.cuda.empty_cache()
 
-        # ... then corrected by measurement: run the step, gather every rank's local time, move the
-        # boundaries so that the measured times come out equal (sd.rebalance_bounds), repeat.
-        bounds_now = [bounds]
-        calib = []
-        for _ in range(max(0, args.calibrate) if world > 1 or args.dist_path else 0):
-            blk = take_block(bounds_now[0])
-            run_block(blk)
-            local_ms = min(run_block(blk)[2] for _ in range(3))        # best of three: the timer noise is about 1 ms
-            mine = torch.tensor([local_ms], dtype=torch.float64, device=coll_dev)
-            every = [torch.empty(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
-            dist.all_gather(every, mine)
-            times = [float(x[0]) for x in every]
-            calib.append([round(x, 2) for x in times])
-            bounds_now[0] = sd.rebalance_bounds(bounds_now[0], cost_prefix, times, min_gain=0.015)
-            del blk
-        bounds = bounds_now[0]
-        block = take_block(bounds)
-        del raw0, raw1, rawv, cost_prefix
-        torch.cuda.empty_cache()
-
-        def step():
-            res, remote, _ = run_block(block)
-            return res, remote
+    def step():
+        res, remote, _ = run_block(block)
+        return res, remote
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -256,84 +389,161 @@ def main():
     elapsed = time.perf_counter() - t0
 
     res, remote = results[-1]
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
-        stats = torch.tensor([res.nnz_a, res.products, remote], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(stats)
-        nnz_a, products, remote_total = [int(x) for x in stats.tolist()]
-        nnz_c, vsum, vhash = sd.reduce_digest(int(res.nnz), float(res.sum), int(res.hash), coll_dev)
-    else:
-        nnz_a, products, remote_total = int(res.nnz_a), int(res.products), 0
-        nnz_c, vsum, vhash = int(res.nnz), float(res.sum), int(res.hash)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+    stats = torch.tensor([res.nnz_a, res.products, remote], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(stats)
+    nnz_a, products, remote_total = [int(x) for x in stats.tolist()]
+    nnz_c, vsum, vhash = sd.reduce_digest(int(res.nnz), float(res.sum), int(res.hash), coll_dev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        # dominant kernel of rank 0 = the numeric kernel with the largest duration, timed with HIP
-        # events on the library's stream in every step.  Algorithmic bytes of one launch =
-        # 12 B per scalar product it processes + 16 B per A tuple of its rows.
-        def avg(f):
-            return sum(f(r[0]) for r in results) / len(results)
-        p_hash = res.products_heavy - res.products_dense
-        t_heavy = max(1, res.products_heavy)
-        kernels = [
-            ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, res.tuples_heavy * res.products_dense / t_heavy),
-            ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense), p_hash, res.tuples_heavy * p_hash / t_heavy),
-            ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
-            ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
-        ]
-        name, ms_kernel, k_prod, k_tup = max(kernels, key=lambda k: k[1])
-        alg_bytes = int(16 * k_tup + 12 * k_prod)
-        achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (bench.py cannot run the profiler on itself); null when no pass covers the kernel
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if args.workload == "rmat" and scale == 20 and world == 1 and name in pmc["kernels"]:
-                traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        line = {
-            "metric": "nnz(C)/s for C=A*A SpGEMM",
-            "value": nnz_c * args.steps / elapsed,
-            "unit": "nnz(C)/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_step,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": wname,
-                "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
-                "parallelism": "1 GPU" if world == 1 else "%d row blocks (per-row cost estimate, then %d measure/rebalance rounds) + all-to-allv of B row panels" % (world, len(calib)),
-                "remote_panel_tuples": remote_total,
-                "calibration_local_ms": calib if use_dist else None,
-                "digest": {"sum": vsum, "hash": "%016x" % vhash},
-                "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,
-                "products_per_s": products / (ms_step * 1e-3),
-                "stage_ms_rank0": {"consolidate": res.ms_consolidate, "symbolic": res.ms_symbolic, "numeric": res.ms_numeric,
-                                   "light": res.ms_light, "mid": res.ms_mid, "heavy_hash_cells": res.ms_heavy - res.ms_dense,
-                                   "heavy_dense_cells": res.ms_dense},
-                "rows_rank0": {"light": res.rows_light, "mid": res.rows_mid, "heavy": res.rows_heavy,
-                               "hash_cells": res.cells_hash, "dense_cells": res.cells_dense},
-            },
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_scale, seed)
+        line = headline(args, world, wname, n, ne, nnz_a, products, nnz_c, vsum, vhash, ms_step, elapsed,
+                        [r[0] for r in results], remote_total, calib,
+                        "%d row blocks (per-row cost estimate, then %d measure/rebalance rounds) + all-to-allv of B row panels" % (world, len(calib)))
         print(json.dumps(line), flush=True)
     ctx.close()
-    if use_dist:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
+    finish()
+
+
+def roofline_of(args, world, results, scale_is_cfg2):
+    """Dominant kernel of rank 0 = the numeric kernel with the largest duration, timed with HIP events on the
+    library's stream in every step.  Algorithmic bytes of one launch = 12 B per scalar product it
+    processes + 16 B per A tuple of its rows."""
+    res = results[-1]
+
+    def avg(f):
+        return sum(f(r) for r in results) / len(results)
+    p_hash = res.products_heavy - res.products_dense
+    t_heavy = max(1, res.products_heavy)
+    kernels = [
+        ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, res.tuples_heavy * res.products_dense / t_heavy),
+        ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense), p_hash, res.tuples_heavy * p_hash / t_heavy),
+        ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
+        ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
+    ]
+    name, ms_kernel, k_prod, k_tup = max(kernels, key=lambda k: k[1])
+    alg_bytes = int(16 * k_tup + 12 * k_prod)
+    achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+    # HBM-side bytes per launch: bench.py cannot run the profiler on itself, so this is the figure of the
+    # committed rocprofv3 --pmc passes of this same command (file and commit named beside it); null when no
+    # pass covers the kernel.  It is a constant of that profiled run, NOT a measurement of this run.
+    traffic, source = None, None
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            pmc = json.load(f)
+        if scale_is_cfg2 and world == 1 and name in pmc["kernels"]:
+            traffic = pmc["kernels"][name]["traffic_bytes_per_launch"]
+            source = "%s (rocprofv3 --pmc passes of `%s`, build %s; constant of that run)" % (
+                PMC_FILE, pmc.get("command", "python bench.py"), pmc.get("commit", "?"))
+    except (OSError, KeyError, ValueError):
+        traffic = None
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
+            "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel,
+            "all_kernels_ms": {k[0]: k[1] for k in kernels}}
+
+
+def headline(args, world, wname, n, ne, nnz_a, products, nnz_c, vsum, vhash, ms_step, elapsed, results, remote_total, calib, par):
+    res = results[-1]
+    return {
+        "metric": "nnz(C)/s for C=A*A SpGEMM",
+        "value": nnz_c * args.steps / elapsed,
+        "unit": "nnz(C)/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": wname,
+            "n": n, "raw_tuples": ne, "nnz_a": nnz_a, "products": products, "nnz_c": nnz_c,
+            "parallelism": par,
+            "remote_panel_tuples": remote_total,
+            "calibration_local_ms": calib,
+            "digest": {"sum": vsum, "hash": "%016x" % vhash},
+            "read_alg_GBps": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9,
+            "read_alg_frac_of_hbm_peak": (16 * nnz_a + 12 * products) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "products_per_s": products / (ms_step * 1e-3),
+            "stage_ms_rank0": {"consolidate": res.ms_consolidate, "symbolic": res.ms_symbolic, "numeric": res.ms_numeric,
+                               "light": res.ms_light, "mid": res.ms_mid, "heavy_hash_cells": res.ms_heavy - res.ms_dense,
+                               "heavy_dense_cells": res.ms_dense},
+            "rows_rank0": {"light": res.rows_light, "mid": res.rows_mid, "heavy": res.rows_heavy,
+                           "hash_cells": res.cells_hash, "dense_cells": res.cells_dense},
+        },
+        "roofline": roofline_of(args, world, results, args.workload == "rmat" and args.scale == 20),
+    }
+
+
+def single_gpu(args, torch, capi, ctx, dev, stream):
+    """N = 1: the headline workload, then (default run only) the other configs in the same process."""
+    w = Workload(torch, capi, ctx, dev, args.workload, args.scale, args.grid, args.seed, args.sink)
+    summary, results = run_workload(torch, w, args.steps, args.warmup)
+    last = results[-1]
+    flat = [r for step in results for r in step] if w.kind == "galerkin" else [step[0] for step in results]
+    nnz_a, products, nnz_c = sum(summary["nnz_a"]), sum(summary["products"]), summary["nnz_c"][-1]
+    elapsed = summary["ms_per_step"] * 1e-3 * args.steps
+    line = headline(args, 1, w.name, w.n, w.ne, nnz_a, products, nnz_c,
+                    float(last[-1].sum), int(last[-1].hash), summary["ms_per_step"], elapsed,
+                    [step[-1] for step in results] if w.kind == "galerkin" else flat, 0, None, "1 GPU")
+    if w.kind == "galerkin":
+        line["metric"] = "nnz(C)/s for C=R*A*R^T (two chained SpGEMMs)"
+        line["config"]["multiplies"] = summary
+    if w.sink_name == "coo":
+        line["config"]["read_write_alg_GBps"] = summary["read_write_alg_GBps"]
+    line["config"]["workspace_GB"] = summary["workspace_GB"]
+    w.release()
+    ctx.close()                                   # the headline's workspace goes back before the other configs run
+    default_line = args.workload == "rmat" and args.scale == 20 and args.sink == "digest"
+    if default_line and not args.no_other_configs:
+        others = {}
+
+        def other(key, kind, steps, warmup, **kw):
+            c2 = capi.Context(dev.index, stream.cuda_stream)           # fresh workspace per config
+            try:
+                w2 = Workload(torch, capi, c2, dev, kind, **kw)
+                others[key] = run_workload(torch, w2, steps, warmup)[0]
+                w2.release()
+            except Exception as e:                                      # a failing extra config must not lose the headline
+                others[key] = {"error": repr(e)}
+            finally:
+                c2.close()
+                torch.cuda.empty_cache()
+
+        other("cfg3_poisson4096_digest", "poisson", 10, 2, grid=4096)
+        other("cfg3_poisson4096_coo", "poisson", 10, 2, grid=4096, sink="coo")
+        other("cfg5_galerkin256_coo", "galerkin", 5, 1, grid=256)
+        other("cfg2_rmat20_coo_sink", "rmat", 2, 1, scale=20, seed=args.seed, sink="coo")
+        other("cfg4_rmat23_one_gpu_digest", "rmat", 2, 1, scale=23, seed=args.seed)
+        try:
+            c3 = capi.Context(dev.index, stream.cuda_stream)
+            others["pcie_inclusive_host_delivery"] = pcie_delivery(torch, capi, c3, dev, 17, args.seed)
+            c3.close()
+        except Exception as e:
+            others["pcie_inclusive_host_delivery"] = {"error": repr(e)}
+        line["other_configs"] = others
+        coo = others.get("cfg2_rmat20_coo_sink", {})
+        if "ms_per_step" in coo:
+            line["config"]["coo_sink_ms_per_step"] = coo["ms_per_step"]
+            line["config"]["coo_sink_nnz_c_per_s"] = coo["nnz_c_per_s"]
+    if not args.no_cpu_baseline and default_line:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.seed)
+    return line
+
+
+def finish():
+    """Leave nothing behind: flush, then end the process without the interpreter's slow teardown (hundreds of
+    idle OpenMP workers of the CPU baseline, the HIP runtime's unmapping of ~200 GB) so that no child or
+    lingering process outlives the bench line."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -99,10 +99,16 @@ typedef struct {
                                    * any input, several times slower on rows with more than 64 products */
 
 /*
- * Result of one multiply.  For SINK_COO the three arrays live in the context's
- * output buffer (device memory) and stay valid until the next multiply or
- * spsamd_ctx_destroy on that context; tuples are in ascending (i, j), each
- * (i, j) at most once, exact zeros dropped (multiply_sparse.hpp:238).
+ * Result of one multiply.  For SINK_COO the three arrays live in one of the
+ * context's two output buffers (device memory) and stay valid until the next
+ * SINK_COO multiply / consolidate or spsamd_ctx_destroy on that context;
+ * tuples are in ascending (i, j), each (i, j) at most once, exact zeros dropped
+ * (multiply_sparse.hpp:238).
+ * Chaining: the arrays may be handed straight back as a SPSAMD_MEM_DEVICE,
+ * sort0 = 0 operand of the NEXT call on the same context (T = R*A, then
+ * C = T*R^T): that call reads them in place and writes its own result to the
+ * other buffer, so no copy and no re-consolidation of T takes place; T stays
+ * valid until the call after that.
  */
 typedef struct {
 	uint64_t shape0, shape1;      /* ret.set_shape(), multiply_sparse.hpp:169 */
@@ -122,7 +128,7 @@ typedef struct {
 	 * light P_r <= 64, mid <= 4096, heavy above */
 	float ms_light, ms_mid, ms_heavy;
 	float ms_dense;               /* part of ms_heavy spent in the dense-window kernel */
-	uint32_t pad_;
+	uint32_t window;              /* column-window width the heavy rows were cut with (8192 / 16384; 0 = no heavy row) */
 	uint64_t cells_hash, cells_dense;   /* heavy rows are cut into cells: LDS-hash cells and dense-window cells */
 	uint64_t products_dense;            /* products of the dense-window cells (part of products_heavy) */
 	uint64_t workspace_bytes;           /* device workspace this call carved from the context's arena */
@@ -141,6 +147,11 @@ const char *spsamd_last_error(const spsamd_ctx *ctx);
 /* pre-size the workspace (bytes); optional, it grows on demand otherwise */
 int spsamd_ctx_reserve(spsamd_ctx *ctx, size_t workspace_bytes, size_t output_tuples);
 const char *spsamd_version(void);
+/* Developer knobs ("window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path",
+ * "bwin_budget_mb"; value 0 = default).  They select between equivalent kernels / tile sizes: the result
+ * of a multiply is the same for every setting.  The environment variables of the same purpose
+ * (SPSAMD_W ...) are read once, inside spsamd_ctx_create; nothing reads the environment later. */
+int spsamd_ctx_set_tuning(spsamd_ctx *ctx, const char *name, long value);
 
 /*
  * ret = C * diag(scalei) * op(A) * diag(scalej) * op(B) * diag(scalek)
@@ -165,7 +176,8 @@ int spsamd_multiply(spsamd_ctx *ctx, double C,
  * ret = C * diag(scalei) * op(A) * diag(scalej) * V
  * -- spsparse::multiply, matrix x sparse vector (multiply_sparse.hpp:281-365).
  * V is consolidated with sort order {0} (:313).  The result is rank 1:
- * result->idx0 holds the row indices, idx1 is all zero, shape1 is 0.
+ * result->idx0 holds the row indices, idx1 is NULL (spsamd_result_fetch then
+ * passes j = NULL to the callback), shape1 is 0.
  */
 int spsamd_multiply_mv(spsamd_ctx *ctx, double C,
 	const spsamd_vec *scalei,

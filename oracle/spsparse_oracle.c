@@ -491,12 +491,30 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 		return -2;
 	}
 
-	/* A sorted by rows of op(A); B sorted by ROWS of op(B) (the inner index):
-	 * a stable sort keeps duplicates in insertion order either way, so the
-	 * consolidated values equal those of the reference's column-major copy. */
-	conmat Ac, Bc;
+	/* A sorted by rows of op(A).  B: consolidated exactly as the reference does it, by its
+	 * own (column-major of op(B)) sort order b0 -- which tuples zero_nan drops depends on that
+	 * sequence (algorithm.hpp:272-275 vs :284-292) -- and THEN put in rows-of-op(B) order by a
+	 * plain stable sort that drops and merges nothing (explicit zeros left by a +x/-x merge
+	 * stay, as they do in the reference's copy). */
+	conmat Ac, Bc, Bref;
 	conmat_build(&Ac, A, a0, duplicate_policy, zero_nan);
-	conmat_build(&Bc, B, b1, duplicate_policy, zero_nan);
+	conmat_build(&Bref, B, b0, duplicate_policy, zero_nan);
+	{
+		/* Bref: lead = index(b0), minor = index(b1); re-sort by (minor, lead) */
+		size_t nb = Bref.n;
+		size_t *perm = (size_t *)xmalloc((nb ? nb : 1) * sizeof(size_t));
+		orc_sorted_permutation(2, Bref.minor, Bref.lead, nb, 0, perm);
+		orc_mat tmp;
+		int32_t *t0 = (int32_t *)xmalloc((nb ? nb : 1) * sizeof(int32_t));
+		int32_t *t1 = (int32_t *)xmalloc((nb ? nb : 1) * sizeof(int32_t));
+		double *tv = (double *)xmalloc((nb ? nb : 1) * sizeof(double));
+		for (size_t e = 0; e < nb; ++e) { t0[e] = Bref.minor[perm[e]]; t1[e] = Bref.lead[perm[e]]; tv[e] = Bref.val[perm[e]]; }
+		tmp.idx0 = t0; tmp.idx1 = t1; tmp.val = tv; tmp.nnz = nb;
+		tmp.shape0 = bshape[b1]; tmp.shape1 = bshape[b0]; tmp.sort0 = 0;      /* trusted as is: nothing dropped */
+		conmat_build(&Bc, &tmp, 0, duplicate_policy, 0);
+		free(perm); free(t0); free(t1); free(tv);
+		conmat_free(&Bref);
+	}
 
 	/* row pointer of op(B) over all inner indices */
 	size_t *bptr = (size_t *)xmalloc((ninner + 1) * sizeof(size_t));

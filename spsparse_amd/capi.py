@@ -49,7 +49,7 @@ class Result(C.Structure):
                 ("row_nnz", C.c_void_p), ("row_sum", C.c_void_p),
                 ("ms_consolidate", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float),
                 ("ms_total", C.c_float), ("ms_light", C.c_float), ("ms_mid", C.c_float), ("ms_heavy", C.c_float),
-                ("ms_dense", C.c_float), ("pad_", C.c_uint32), ("cells_hash", C.c_uint64), ("cells_dense", C.c_uint64), ("products_dense", C.c_uint64), ("workspace_bytes", C.c_uint64),
+                ("ms_dense", C.c_float), ("window", C.c_uint32), ("cells_hash", C.c_uint64), ("cells_dense", C.c_uint64), ("products_dense", C.c_uint64), ("workspace_bytes", C.c_uint64),
                 ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
                 ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64),
                 ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64)]
@@ -58,7 +58,7 @@ class Result(C.Structure):
 CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_size_t)
 
 # every symbol include/spsparse_amd.h declares
-SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version",
+SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version", "spsamd_ctx_set_tuning",
            "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_result_scatter_dense", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
            "spsamd_dim_beginnings", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
@@ -92,6 +92,7 @@ def load():
     L.spsamd_last_error.restype = C.c_char_p
     L.spsamd_ctx_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
     L.spsamd_version.restype = C.c_char_p
+    L.spsamd_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     L.spsamd_multiply.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Coo), C.c_char, P(Vec),
                                   C.c_int, C.c_int, C.c_int, C.c_int, P(Result)]
     L.spsamd_multiply_mv.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Vec),
@@ -125,6 +126,12 @@ def device_coo(ptr0, ptr1, ptrv, nnz, shape, sort0=-1):
     return Coo(ptr0, ptr1, ptrv, nnz, int(shape[0]), int(shape[1]), sort0, MEM_DEVICE)
 
 
+def result_operand(res):
+    """A SINK_COO result as the device operand of the NEXT call on the same context (read in place:
+    sorted row-major, each index once -- sort0 = 0, so it is trusted like Consolidate<> does)."""
+    return Coo(res.idx0, res.idx1, res.val, int(res.nnz), int(res.shape0), int(res.shape1), 0, MEM_DEVICE)
+
+
 def host_vec(idx, val, shape0, sort0=-1):
     a = np.ascontiguousarray(idx, dtype=np.int32)
     v = np.ascontiguousarray(val, dtype=np.float64)
@@ -156,6 +163,10 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise SpsamdError(rc, self.L.spsamd_last_error(self.h).decode())
+
+    def set_tuning(self, name, value):
+        """Developer knob (spsamd_ctx_set_tuning): selects between equivalent kernels, never changes a result."""
+        self._check(self.L.spsamd_ctx_set_tuning(self.h, name.encode(), int(value)))
 
     def reserve(self, workspace_bytes=0, output_tuples=0):
         self._check(self.L.spsamd_ctx_reserve(self.h, workspace_bytes, output_tuples))
@@ -205,7 +216,10 @@ class Context:
         def cb(_user, pi, pj, pv, cnt):
             o = pos[0]
             oi[o:o + cnt] = np.ctypeslib.as_array(pi, shape=(cnt,))
-            oj[o:o + cnt] = np.ctypeslib.as_array(pj, shape=(cnt,))
+            if pj:                                                      # NULL for a rank-1 (MV) result
+                oj[o:o + cnt] = np.ctypeslib.as_array(pj, shape=(cnt,))
+            else:
+                oj[o:o + cnt] = 0
             ov[o:o + cnt] = np.ctypeslib.as_array(pv, shape=(cnt,))
             pos[0] = o + cnt
             return 0

@@ -5,6 +5,7 @@
 #include "internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <exception>
@@ -40,8 +41,29 @@ extern "C" int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream)
 		c->own_stream = true;
 	}
 	for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return SPSAMD_EHIP; }
+	// developer knobs: the environment is consulted here and nowhere else
+	static const char *const knobs[] = {"window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path", "bwin_budget_mb"};
+	static const char *const envs[] = {"SPSAMD_W", "SPSAMD_CELL_CAP", "SPSAMD_DENSE_MIN", "SPSAMD_NO_TILES", "SPSAMD_XCD", "SPSAMD_EMIT_PATH", "SPSAMD_LIGHT_PATH", "SPSAMD_BWIN_BUDGET_MB"};
+	for (size_t k = 0; k < sizeof knobs / sizeof knobs[0]; ++k)
+		if (const char *e = getenv(envs[k])) (void)spsamd_ctx_set_tuning(c, knobs[k], atol(e));
+#ifdef SPSAMD_ABLATIONS
+	if (const char *e = getenv("SPSAMD_DBG")) c->tune.dbg = atoi(e);
+#endif
 	*out = c;
 	return SPSAMD_OK;
+}
+
+extern "C" int spsamd_ctx_set_tuning(spsamd_ctx *c, const char *name, long value)
+{
+	if (!c || !name) return SPSAMD_EINVAL;
+	struct { const char *n; int *p; } tab[] = {
+		{"window", &c->tune.window}, {"cell_cap", &c->tune.cell_cap}, {"dense_min", &c->tune.dense_min},
+		{"no_tiles", &c->tune.no_tiles}, {"xcd", &c->tune.xcd}, {"emit_path", &c->tune.emit_path},
+		{"light_path", &c->tune.light_path}, {"bwin_budget_mb", &c->tune.bwin_budget_mb},
+	};
+	for (auto &t : tab) if (!std::strcmp(t.n, name)) { *t.p = (int)value; return SPSAMD_OK; }
+	c->last_error = std::string("unknown tuning knob: ") + name;
+	return SPSAMD_EINVAL;
 }
 
 extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
@@ -50,7 +72,7 @@ extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	c->arena.release();
-	c->out_i.release(); c->out_j.release(); c->out_v.release();
+	c->out[0].release(); c->out[1].release();
 	c->rowstat_n.release(); c->rowstat_s.release();
 	if (c->pinned) (void)hipHostFree(c->pinned);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -67,12 +89,28 @@ extern "C" int spsamd_ctx_reserve(spsamd_ctx *c, size_t workspace_bytes, size_t 
 		SPS_HIP(hipSetDevice(c->device));
 		if (workspace_bytes) c->arena.reserve(workspace_bytes);
 		if (output_tuples) {
-			c->out_i.ensure(output_tuples * sizeof(int32_t));
-			c->out_j.ensure(output_tuples * sizeof(int32_t));
-			c->out_v.ensure(output_tuples * sizeof(double));
+			OutSet &o = c->out[c->cur_out];
+			o.i.ensure(output_tuples * sizeof(int32_t));
+			o.j.ensure(output_tuples * sizeof(int32_t));
+			o.v.ensure(output_tuples * sizeof(double));
 		}
 		return SPSAMD_OK;
 	)
+}
+
+void spsamd::pick_output_set(spsamd_ctx *c, const spsamd_coo *const *operands, int n)
+{
+	auto aliased = [&](int s) {
+		for (int k = 0; k < n; ++k) {
+			const spsamd_coo *X = operands[k];
+			if (X && X->mem == SPSAMD_MEM_DEVICE && (c->out[s].holds(X->idx0) || c->out[s].holds(X->idx1) || c->out[s].holds(X->val))) return true;
+		}
+		return false;
+	};
+	if (!aliased(c->cur_out)) return;
+	if (aliased(c->cur_out ^ 1))
+		throw Error{SPSAMD_EINVAL, "both result buffers of this context are operands of the call: copy one of them out first (spsamd_memcpy)"};
+	c->cur_out ^= 1;
 }
 
 static bool same_operand(const spsamd_coo *a, const spsamd_coo *b)
@@ -113,11 +151,14 @@ static int multiply_body(spsamd_ctx *c, double C,
 	if (!arena_ready) c->arena.reset();
 	hipStream_t st = c->stream;
 	SPS_HIP(hipEventRecord(c->ev[0], st));
+	if (sink_kind == SPSAMD_SINK_COO) { const spsamd_coo *ops[2] = {A, B}; pick_output_set(c, ops, 2); }
 	MultiplyArgs a;
 	a.C = C; a.sink_kind = sink_kind; a.sink_flags = sink_flags;
-	consolidate_operand(c, A, a0, duplicate_policy, zero_nan, &a.A);          // :187
-	if (a0 == bk && same_operand(A, B)) a.B = a.A;                             // A*A: one consolidation serves both
-	else consolidate_operand(c, B, bk, duplicate_policy, zero_nan, &a.B);      // :188
+	consolidate_operand(c, A, a0, a0, duplicate_policy, zero_nan, &a.A);      // :187
+	// A*A: one consolidation serves both -- except under zero_nan, where the NaNs dropped from B are those
+	// of the leading run of the reference's column-major sequence (:168), not of A's row-major one
+	if (a0 == bk && same_operand(A, B) && !zero_nan) a.B = a.A;
+	else consolidate_operand(c, B, bk, bj, duplicate_policy, zero_nan, &a.B);  // :188
 	upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
 	upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
 	upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
@@ -178,6 +219,7 @@ extern "C" int spsamd_multiply_mv(spsamd_ctx *c, double C,
 		int rc = multiply_body(c, C, scalei, A, transpose_A, scalej, &Vm, '.', nullptr, duplicate_policy, zero_nan,
 			sink_kind, sink_flags & ~SPSAMD_SINK_PERMUTE, res, "V", true);     // a rank-1 result has nothing to permute
 		res->shape1 = 0;                              // rank-1 result: ret.set_shape({rows}) (:295)
+		res->idx1 = nullptr;                          // ... with one index array: nothing to copy for a second one
 		return rc;
 	)
 }
@@ -273,17 +315,20 @@ extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, i
 		spsamd_coo X = *A;
 		X.sort0 = -1;                         // the stand-alone algorithm always runs (algorithm.hpp:251)
 		ConMat m;
-		consolidate_operand(c, &X, so0, duplicate_policy, zero_nan, &m);
+		consolidate_operand(c, &X, so0, so0, duplicate_policy, zero_nan, &m);
 		size_t n = m.nnz;
-		c->out_i.ensure(n * 4 + 4); c->out_j.ensure(n * 4 + 4); c->out_v.ensure(n * 8 + 8);
+		const spsamd_coo *ops[1] = {A};
+		pick_output_set(c, ops, 1);
+		OutSet &o = c->out[c->cur_out];
+		o.i.ensure(n * 4 + 4); o.j.ensure(n * 4 + 4); o.v.ensure(n * 8 + 8);
 		// m.row is the leading (sorted) dimension: put dimensions back in place
-		int32_t *d0 = (int32_t *)c->out_i.p, *d1 = (int32_t *)c->out_j.p;
+		int32_t *d0 = (int32_t *)o.i.p, *d1 = (int32_t *)o.j.p;
 		SPS_HIP(hipMemcpyAsync(so0 == 0 ? d0 : d1, m.row, n * 4, hipMemcpyDeviceToDevice, c->stream));
 		SPS_HIP(hipMemcpyAsync(so0 == 0 ? d1 : d0, m.col, n * 4, hipMemcpyDeviceToDevice, c->stream));
-		SPS_HIP(hipMemcpyAsync(c->out_v.p, m.val, n * 8, hipMemcpyDeviceToDevice, c->stream));
+		SPS_HIP(hipMemcpyAsync(o.v.p, m.val, n * 8, hipMemcpyDeviceToDevice, c->stream));
 		SPS_HIP(hipStreamSynchronize(c->stream));
 		res->nnz = n; res->nnz_a = n;
-		res->idx0 = d0; res->idx1 = d1; res->val = (double *)c->out_v.p;
+		res->idx0 = d0; res->idx1 = d1; res->val = (double *)o.v.p;
 		return SPSAMD_OK;
 	)
 }
@@ -317,7 +362,7 @@ extern "C" int spsamd_dim_beginnings(spsamd_ctx *c, const spsamd_coo *A, int so0
 		SPS_HIP(hipSetDevice(c->device));
 		c->arena.reset();
 		ConMat m;
-		consolidate_operand(c, A, so0, SPSAMD_ADD, 0, &m);         // trusted as is (sort0 == so0): upload only
+		consolidate_operand(c, A, so0, so0, SPSAMD_ADD, 0, &m);         // trusted as is (sort0 == so0): upload only
 		RowList rl;
 		dim_beginnings(c, m, &rl);
 		std::vector<uint32_t> h((size_t)rl.nrows + 1);

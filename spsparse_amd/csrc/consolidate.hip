@@ -46,24 +46,48 @@ __global__ void k_build_keys(const int32_t *major, const int32_t *minor, size_t 
 }
 
 // Gather the values into sorted order and flag the tuples consolidate() keeps:
-// zeros are skipped (algorithm.hpp:284-292).  With zero_nan the first kept
-// tuple is the first that is neither 0 nor NaN (algorithm.hpp:272-275): its
-// position is reduced into *first and applied by k_apply_first.
-__global__ void k_gather_flag(const double *val, const uint32_t *perm, size_t n, int zero_nan,
-	double *sval, uint8_t *keep, uint32_t *first)
+// zeros are skipped (algorithm.hpp:284-292).  With zero_nan the reference also skips the NaNs
+// of the LEADING run of its own sorted sequence (algorithm.hpp:272-275; later NaNs survive, :291).
+// That sequence is ordered by the reference's sort order for this operand, which for B is the
+// other dimension than the one this library sorts by (multiply_sparse.hpp:168,188): the first
+// kept tuple is therefore found as the minimum of (reference key, insertion position) over the
+// tuples that are neither 0 nor NaN -- two atomicMin passes -- and every NaN below it is dropped.
+__device__ __forceinline__ uint64_t ref_key(uint64_t key, int minor_bits, int major_bits, int swap)
+{
+	if (!swap) return key;
+	const uint64_t minor = key & ((uint64_t(1) << minor_bits) - 1), major = key >> minor_bits;
+	return (minor << major_bits) | major;
+}
+
+__global__ void k_gather_flag(const double *val, const uint32_t *perm, const uint64_t *keys, size_t n, int zero_nan,
+	int minor_bits, int major_bits, int swap, double *sval, uint8_t *keep, unsigned long long *first_key)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	double v = val[perm[i]];
 	sval[i] = v;
 	keep[i] = (v != 0) ? 1 : 0;
-	if (zero_nan && v != 0 && v == v) atomicMin(first, (uint32_t)i);
+	if (zero_nan && v != 0 && v == v) atomicMin(first_key, (unsigned long long)ref_key(keys[i], minor_bits, major_bits, swap));
 }
 
-__global__ void k_apply_first(uint8_t *keep, size_t n, const uint32_t *first)
+__global__ void k_first_pos(const double *sval, const uint32_t *perm, const uint64_t *keys, size_t n,
+	int minor_bits, int major_bits, int swap, const unsigned long long *first_key, uint32_t *first_pos)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && i < *first) keep[i] = 0;
+	if (i >= n) return;
+	const double v = sval[i];
+	if (v != 0 && v == v && ref_key(keys[i], minor_bits, major_bits, swap) == *first_key) atomicMin(first_pos, perm[i]);
+}
+
+__global__ void k_apply_first(const double *sval, const uint32_t *perm, const uint64_t *keys, uint8_t *keep, size_t n,
+	int minor_bits, int major_bits, int swap, const unsigned long long *first_key, const uint32_t *first_pos)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const double v = sval[i];
+	if (v == v) return;                                  // only NaNs are in question (zeros are dropped anyway)
+	const uint64_t k = ref_key(keys[i], minor_bits, major_bits, swap), fk = *first_key;
+	if (k < fk || (k == fk && perm[i] < *first_pos)) keep[i] = 0;
 }
 
 __global__ void k_compact(const uint64_t *keys, const double *sval, const uint8_t *keep, const uint32_t *pos, size_t n,
@@ -118,7 +142,7 @@ static const T *to_device(spsamd_ctx *c, const T *p, size_t n, int mem)
 	return d;
 }
 
-void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int duplicate_policy, int zero_nan, ConMat *out)
+void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_lead, int duplicate_policy, int zero_nan, ConMat *out)
 {
 	size_t n = X->nnz;
 	if (n >= (size_t(1) << 31))
@@ -149,7 +173,9 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int dupli
 
 	// Consolidate<>: a matching sort_order is trusted (algorithm.hpp:360); so is
 	// an operand the inspection found strictly sorted with no zero values.
-	if (X->sort0 == lead || !(f & 2u)) {
+	// (Under zero_nan an operand whose reference order is the other dimension and that holds a 0 / NaN
+	// still goes through the filter below: which NaNs go depends on the reference's sequence.)
+	if ((X->sort0 == lead && !(zero_nan && ref_lead != lead && (f & 2u))) || !(f & 2u)) {
 		out->row = const_cast<int32_t *>(major);
 		out->col = const_cast<int32_t *>(minor);
 		out->val = const_cast<double *>(dv);
@@ -169,12 +195,19 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int dupli
 
 	double *sval = c->arena.get<double>(n);
 	uint8_t *keep = c->arena.get<uint8_t>(n);
-	uint32_t *first = flags + 1;
-	fill_u32(c, first, 0xFFFFFFFFu, 1);
-	k_gather_flag<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(dv, ps, n, zero_nan, sval, keep, first);
+	unsigned long long *first_key = c->arena.get<unsigned long long>(1);
+	uint32_t *first_pos = flags + 1;
+	const int swap = ref_lead != lead ? 1 : 0;
+	if (zero_nan) {
+		SPS_HIP(hipMemsetAsync(first_key, 0xFF, sizeof(unsigned long long), c->stream));
+		fill_u32(c, first_pos, 0xFFFFFFFFu, 1);
+	}
+	k_gather_flag<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(dv, ps, ks, n, zero_nan, mb, Mb, swap, sval, keep, first_key);
 	SPS_LAUNCH_CHECK();
 	if (zero_nan) {
-		k_apply_first<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(keep, n, first);
+		k_first_pos<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(sval, ps, ks, n, mb, Mb, swap, first_key, first_pos);
+		SPS_LAUNCH_CHECK();
+		k_apply_first<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(sval, ps, ks, keep, n, mb, Mb, swap, first_key, first_pos);
 		SPS_LAUNCH_CHECK();
 	}
 	uint32_t *pos = c->arena.get<uint32_t>(n + 1);

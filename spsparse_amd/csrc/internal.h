@@ -52,16 +52,47 @@ struct DevBuf {
 	size_t cap = 0;
 	void ensure(size_t bytes);
 	void release();
+	bool holds(const void *q) const { return p && q && (const char *)q >= (const char *)p && (const char *)q < (const char *)p + cap; }
+};
+
+// One set of SINK_COO / consolidate output arrays.  A context has two: a result handed back as a
+// device operand of the next call (T = R*A, then C = T*R^T: accum.hpp:73-101's use case) is read
+// in place while the new result goes to the other set.
+struct OutSet {
+	DevBuf i, j, v;
+	bool holds(const void *q) const { return i.holds(q) || j.holds(q) || v.holds(q); }
+	void release() { i.release(); j.release(); v.release(); }
 };
 
 } // namespace spsamd
 
+namespace spsamd {
+// Developer knobs of one context.  Read from the environment ONCE, at spsamd_ctx_create
+// (SPSAMD_W, SPSAMD_CELL_CAP, SPSAMD_DENSE_MIN, SPSAMD_NO_TILES, SPSAMD_XCD, SPSAMD_EMIT_PATH),
+// or set through spsamd_ctx_set_tuning; results are identical for every setting.
+struct Tuning {
+	int window = 0;              // 0: chosen from the column count; 8192 / 16384
+	int cell_cap = 0;            // 0: default grouping target of the hash cells
+	int dense_min = 0;           // 0: default threshold above which a window becomes a dense cell
+	int no_tiles = 0;
+	int xcd = 0;
+	int emit_path = 0;           // 0 auto | 1 no bitmap rank | 2 bitonic only
+	int light_path = 0;          // 0 auto | 1 generic k_light only
+	int bwin_budget_mb = 0;      // 0: default cap of the dense window index before the compact index is used
+#ifdef SPSAMD_ABLATIONS
+	int dbg = 0;
+#endif
+};
+}
+
 struct spsamd_ctx {
 	int device = 0;
+	spsamd::Tuning tune;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	spsamd::Arena arena;
-	spsamd::DevBuf out_i, out_j, out_v;      // SINK_COO result
+	spsamd::OutSet out[2];                   // SINK_COO results (see OutSet)
+	int cur_out = 0;
 	spsamd::DevBuf rowstat_n, rowstat_s;     // DIGEST row statistics
 	void *pinned = nullptr;                  // host staging for small readbacks / fetch
 	size_t pinned_cap = 0;
@@ -111,7 +142,9 @@ struct ConMat {
 // Upload (if host) + consolidate `X` by sort order {lead, 1-lead} into `out`
 // (arena memory).  Mirrors Consolidate<> (algorithm.hpp:353-369): an operand
 // whose sort0 == lead is used as is.
-void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int duplicate_policy,
+// `ref_lead` is the leading dimension of the order the REFERENCE consolidates this operand in
+// (it differs from `lead` for B: multiply_sparse.hpp:168); it decides which NaNs zero_nan drops.
+void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_lead, int duplicate_policy,
 	int zero_nan, ConMat *out);
 
 // Row boundaries of a consolidated operand: dim_beginnings (algorithm.hpp:74-118):
@@ -147,5 +180,8 @@ struct MultiplyArgs {
 	int sink_kind, sink_flags;
 };
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res);
+
+// Select the output set the next result is written to: the current one unless a device operand lives in it.
+void pick_output_set(spsamd_ctx *c, const spsamd_coo *const *operands, int n);
 
 } // namespace spsamd

@@ -54,11 +54,21 @@ struct EmitParams {
 	double C;
 	const int32_t *si_pos; const double *si_val;     // row scale (null: none)
 	const int32_t *sk_pos; const double *sk_val;     // column scale (null: none)
-	int dbg;                                         // developer ablation switches (0 in production)
+	int emit_path;                                   // COO emission of hash cells: 0 auto, 1 never the bitmap rank, 2 bitonic network only (same result)
+#ifdef SPSAMD_ABLATIONS
+	int dbg;                                         // profiling builds only: ablation bits that skip work (wrong results on purpose)
+#endif
 	uint32_t wshift;                                 // log2 of the column-window width of the heavy path (0 before it is chosen)
 	uint32_t ncolbits;                               // bits of the largest column index
 	int ordered;                                     // SPSAMD_SINK_ORDERED: ascending-k sums everywhere (bit-exact)
 };
+
+// Ablation switches exist in profiling builds only (-DSPSAMD_ABLATIONS); the shipped library has none.
+#ifdef SPSAMD_ABLATIONS
+#define ABL(ep, bit) ((ep).dbg & (bit))
+#else
+#define ABL(ep, bit) false
+#endif
 
 struct DigestSlot { unsigned long long count; unsigned long long hash; double sum; unsigned long long pad; };
 
@@ -70,6 +80,7 @@ struct SinkParams {
 	int32_t *out_i; int32_t *out_j; double *out_v;
 	DigestSlot *digest;             // DIGEST_SLOTS accumulators
 	long long *row_nnz; double *row_sum;   // optional row statistics (DIGEST)
+	uint32_t *err;                  // device error word: a kernel that meets a state the host promised cannot occur sets a bit
 };
 
 // One B tuple as the numeric kernels read it: column and value side by side (12 bytes), so
@@ -793,7 +804,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		// words + its own word below the bit, and the tuple is stored straight at segoff + rank.
 		const uint32_t colrange = colbits >= 32 ? 0xFFFFFFFFu : (1u << colbits);
 		constexpr int NSB = T / 8;                                         // superblocks of 4 words, one per thread in the scan
-		if (NSB <= NT && colrange <= (uint32_t)T * 32u && !(ep.dbg & 1024)) {
+		if (NSB <= NT && colrange <= (uint32_t)T * 32u && ep.emit_path < 1) {
 			static_assert(NSB <= 16 * EMAX * (NT / 64), "s_cnt holds the superblock prefixes");
 			unsigned long long *bm = (unsigned long long *)s_sort;
 			const uint32_t nwords = (colrange + 63u) >> 6, nsb = (nwords + 3u) >> 2;
@@ -840,7 +851,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			if (tid == 0) sk.segactual[seg] = mcount;
 			return;
 		}
-		if (colbits + PBITS <= 32 && !(ep.dbg & 512)) {
+		if (colbits + PBITS <= 32 && ep.emit_path < 2) {
 			uint32_t *ka = (uint32_t *)s_sort, *kb = ka + T / 2;
 			uint32_t run = 0;
 			for (uint32_t base = 0; base < nocc; base += NT) {
@@ -896,7 +907,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		while (n2 < mcount) n2 <<= 1;
 		for (uint32_t q = mcount + tid; q < n2; q += NT) s_sort[q] = ~0ull;
 		__syncthreads();
-		for (uint32_t k = 2; k <= n2 && !(ep.dbg & 256); k <<= 1) {
+		for (uint32_t k = 2; k <= n2 && !ABL(ep, 256); k <<= 1) {
 			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
 				for (uint32_t i = tid; i < n2; i += NT) {
 					uint32_t ixj = i ^ j;
@@ -980,11 +991,15 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
-		if (cell.prods > (uint32_t)(T / 2)) continue;               // never: the class bounds the cell (guards the LDS tables)
+		// Never: the class bounds the cell (T/2 products fit the LDS tables).  If the host's cell lists ever broke
+		// that promise the cell is skipped as a whole -- the pipeline state below stays consistent -- and the error
+		// word makes the multiply fail instead of returning a wrong product.
+		const bool oversize = cell.prods > (uint32_t)(T / 2);
+		if (oversize && tid == 0) atomicOr(sk.err, 1u);
 		lds_barrier();                                              // previous cell fully emitted, its s_nocc read
 		if (tid == 0) s_nocc = 0;
 
-		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
+		for (uint32_t chunk = beg; chunk < (oversize ? beg : end); chunk += NT) {
 			uint32_t lo = lo0, len = len0; double a = a0;
 			if (chunk != beg) {
 				uint32_t e = chunk + tid;
@@ -999,8 +1014,8 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			uint32_t total, nzc, ex;
 			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 			if (total == 0) continue;
-			if (!(ep.dbg & 4)) expand_batch(X, 0, total, nzc);
-			if (ep.dbg & 1) total = 0;
+			if (!ABL(ep, 4)) expand_batch(X, 0, total, nzc);
+			if (ABL(ep, 1)) total = 0;
 			if (ep.ordered) hash_products_ordered<T, NT, T / 2, MODE>(X, 0, nzc, m, h_key, h_val, occ, &s_nocc);
 			else hash_products<T, NT, T / 2, MODE>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc);
 			lds_barrier();
@@ -1014,7 +1029,7 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		}
 		lds_barrier();
 		uint32_t nocc = s_nocc;
-		if (ep.dbg & 2) nocc = 0;
+		if (ABL(ep, 2)) nocc = 0;
 		uint32_t colbase = 0, colbits = ep.ncolbits;
 		if (WINDOWED) { colbase = wa << ep.wshift; colbits = ep.wshift + (wb - wa > 1 ? 32 - __builtin_clz(wb - wa - 1) : 0); }
 		hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
@@ -1472,7 +1487,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			uint32_t total, nzc, ex;
 			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 			if (total == 0) continue;                               // uniform
-			if (ep.dbg & 8) total = 0;
+			if (ABL(ep, 8)) total = 0;
 			if (ep.ordered && MODE != MODE_COUNT) {
 				// ascending-k accumulation, one segment (unique columns) at a time: see hash_products_ordered
 				lds_barrier();                                      // the compacted segments are visible
@@ -1541,7 +1556,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			const uint32_t lo = bw[0], hi = bw[1];
 			nlo = lo; nlen = nact ? hi - lo : 0u;
 		}
-		if (ep.dbg & 16) continue;
+		if (ABL(ep, 16)) continue;
 		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
 		double v[GPW];
 		uint64_t nzmask[GPW];
@@ -1602,9 +1617,10 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 
 // ====================================================================== holes (cancellation in STORE)
 
-__global__ void k_seg_holes(const uint32_t *segcount, const uint32_t *segactual, uint32_t nseg, unsigned long long *holes)
+__global__ void k_seg_holes(const uint32_t *segcount, const uint32_t *segactual, uint32_t nseg, unsigned long long *holes, const uint32_t *err)
 {
 	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s == 0) holes[1] = *err;                                // rides along with the read-back of the hole count
 	unsigned long long d = 0;
 	if (s < nseg) d = (unsigned long long)(segcount[s] - segactual[s]);
 	d = wave_reduce_sum(d);
@@ -1621,13 +1637,13 @@ __global__ void k_seg_gather(const int64_t *oldoff, const int64_t *newoff, const
 	for (uint32_t t = 0; t < n; ++t) { di[b + t] = si[a + t]; dj[b + t] = sj[a + t]; dv[b + t] = sv[a + t]; }
 }
 
-__global__ void k_digest_reduce(const DigestSlot *slots, DigestSlot *out)
+__global__ void k_digest_reduce(const DigestSlot *slots, DigestSlot *out, const uint32_t *err)
 {
 	// one wave; deterministic order of the slot sums
 	unsigned long long c = 0, h = 0; double s = 0;
 	for (int q = threadIdx.x; q < DIGEST_SLOTS; q += 64) { c += slots[q].count; h += slots[q].hash; s += slots[q].sum; }
 	c = wave_reduce_sum(c); h = wave_reduce_sum(h); s = wave_reduce_sum(s);
-	if (threadIdx.x == 0) { out->count = c; out->hash = h; out->sum = s; }
+	if (threadIdx.x == 0) { out->count = c; out->hash = h; out->sum = s; out->pad = *err; }
 }
 
 // ====================================================================== host driver
@@ -1746,7 +1762,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 {
 	hipStream_t st = c->stream;
 	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
-	if (const char *e = getenv("SPSAMD_W")) { int v = atoi(e); if (v == 8192 || v == 16384) hv.W = v; }
+	if (c->tune.window == 8192 || c->tune.window == 16384) hv.W = c->tune.window;
 	const uint32_t wshift = hv.W == 8192 ? 13 : 14;
 	hv.nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
 	if (hv.nwin > (uint32_t)WH_MAXW) throw Error{SPSAMD_EINVAL, "too many column windows (ncol > 2^25) for the heavy-row path"};
@@ -1774,12 +1790,12 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
 		hv.base.base[k] = c->arena.get<uint32_t>((size_t)hv.n + 1);
 	}
-	if (const char *e = getenv("SPSAMD_CELL_CAP")) { int v = atoi(e); if (v >= 64 && v <= (int)CELL_CAP) hv.cell_cap = (uint32_t)v; }
-	if (const char *e = getenv("SPSAMD_DENSE_MIN")) { int v = atoi(e); if (v >= 64 && v <= (int)CELL_CAP) hv.dense_min = (uint32_t)v; }
+	if (c->tune.cell_cap >= 64 && c->tune.cell_cap <= (int)CELL_CAP) hv.cell_cap = (uint32_t)c->tune.cell_cap;
+	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
 	if (hv.dense_min < hv.cell_cap) hv.dense_min = hv.cell_cap;
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
-	hv.tb.enabled = !(getenv("SPSAMD_NO_TILES") && atoi(getenv("SPSAMD_NO_TILES")));
+	hv.tb.enabled = !c->tune.no_tiles;
 	hv.tb.pb = hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB;
 	hv.tb.ntc = c->arena.get<uint32_t>(hv.n); hv.tb.ntl = c->arena.get<uint32_t>(hv.n);
 	hv.tb.tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); hv.tb.tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
@@ -1835,7 +1851,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	// Measured on R-MAT scale-20: giving each XCD its own part of the list is SLOWER (dense 80 vs
 	// 57 ms, hash 73 vs 62 ms) than letting all XCDs walk the same windows together, so the
 	// partition stays an experiment behind SPSAMD_XCD=1.
-	static const bool xcd_aware = getenv("SPSAMD_XCD") && atoi(getenv("SPSAMD_XCD"));
+	const bool xcd_aware = c->tune.xcd != 0;
 	for (int k = 0; k < NCLS && xcd_aware; ++k) {
 		uint32_t nd = hv.ncell[k];
 		if (nd < 4096) continue;
@@ -1929,7 +1945,11 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	SPS_LAUNCH_CHECK();
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
-		getenv("SPSAMD_DBG") ? atoi(getenv("SPSAMD_DBG")) : 0, 0u,
+		c->tune.emit_path,
+#ifdef SPSAMD_ABLATIONS
+		c->tune.dbg,
+#endif
+		0u,
 		B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u,
 		(a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0};
 
@@ -1963,12 +1983,15 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	}
 	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3] + hv.ntcell;
 	res->cells_dense = hv.ncell[CLS_DENSE];
+	res->window = hv.n ? (uint32_t)hv.W : 0u;
 	res->products_dense = hv.clsprod[CLS_DENSE];
 	SPS_HIP(hipEventRecord(c->ev[2], st));
 
 	// ---- numeric
 	SinkParams sk{};
 	sk.segbase = segbase;
+	sk.err = c->arena.get<uint32_t>(1);
+	fill_zero(c, sk.err, sizeof(uint32_t));
 	float ms_light = 0, ms_mid = 0, ms_heavy = 0, ms_dense = 0;
 	if (!coo) {
 		DigestSlot *slots = c->arena.get<DigestSlot>(DIGEST_SLOTS + 1);
@@ -1993,9 +2016,10 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		SPS_HIP(hipEventRecord(c->ev[6], st));
 		launch_heavy_dense<MODE_DIGEST>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[8], st));
-		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS);
+		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS, sk.err);
 		SPS_LAUNCH_CHECK();
 		DigestSlot d = read_back(c, slots + DIGEST_SLOTS);
+		if (d.pad) throw Error{SPSAMD_EINVAL, "internal error: a numeric kernel met a cell larger than its class allows"};
 		res->nnz = d.count; res->hash = d.hash; res->sum = d.sum;
 		ms_light = elapsed(c->ev[3], c->ev[4]); ms_mid = elapsed(c->ev[4], c->ev[5]);
 		ms_heavy = elapsed(c->ev[5], c->ev[8]); ms_dense = elapsed(c->ev[6], c->ev[8]);
@@ -2014,10 +2038,11 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		launch_heavy_dense<MODE_COUNT>(c, hv, m, ep, sk);
 		scan_exclusive_u32_i64(c, segcount, segoff, (size_t)nsegs);
 		int64_t reserved = read_back(c, segoff + nsegs);
-		c->out_i.ensure((size_t)reserved * sizeof(int32_t));
-		c->out_j.ensure((size_t)reserved * sizeof(int32_t));
-		c->out_v.ensure((size_t)reserved * sizeof(double));
-		sk.out_i = (int32_t *)c->out_i.p; sk.out_j = (int32_t *)c->out_j.p; sk.out_v = (double *)c->out_v.p;
+		OutSet &os = c->out[c->cur_out];              // chosen by multiply_body: never the set an operand lives in
+		os.i.ensure((size_t)reserved * sizeof(int32_t));
+		os.j.ensure((size_t)reserved * sizeof(int32_t));
+		os.v.ensure((size_t)reserved * sizeof(double));
+		sk.out_i = (int32_t *)os.i.p; sk.out_j = (int32_t *)os.j.p; sk.out_v = (double *)os.v.p;
 		SPS_HIP(hipEventRecord(c->ev[4], st));
 		launch_light<MODE_STORE>(c, bins, m, ep, sk);
 		launch_mid<MODE_STORE>(c, bins, mc, m, ep, sk);
@@ -2026,11 +2051,14 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		SPS_HIP(hipEventRecord(c->ev[6], st));
 		launch_heavy_dense<MODE_STORE>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[8], st));
-		unsigned long long *holes = c->arena.get<unsigned long long>(1);
-		fill_zero(c, holes, sizeof(unsigned long long));
-		k_seg_holes<<<dim3(grid_for((size_t)nsegs)), dim3(256), 0, st>>>(segcount, segactual, (uint32_t)nsegs, holes);
+		struct HolesErr { unsigned long long holes, err; };
+		unsigned long long *holes = c->arena.get<unsigned long long>(2);
+		fill_zero(c, holes, 2 * sizeof(unsigned long long));
+		k_seg_holes<<<dim3(grid_for((size_t)nsegs)), dim3(256), 0, st>>>(segcount, segactual, (uint32_t)nsegs, holes, sk.err);
 		SPS_LAUNCH_CHECK();
-		unsigned long long nholes = read_back(c, holes);
+		const HolesErr he = read_back(c, (const HolesErr *)holes);
+		if (he.err) throw Error{SPSAMD_EINVAL, "internal error: a numeric kernel met a cell larger than its class allows"};
+		unsigned long long nholes = he.holes;
 		uint64_t nnz = (uint64_t)reserved - nholes;
 		if (nholes) {
 			// sums that cancelled to exactly 0 left gaps: close them (rare path)

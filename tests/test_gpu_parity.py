@@ -313,6 +313,38 @@ def test_fuzz_nan_values_and_zero_nan(ctx):
         assert np.allclose(g2[2][ok], want[2][ok], rtol=1e-12, atol=0)
 
 
+def test_zero_nan_follows_the_references_sequence_for_b(ctx):
+    """which NaNs zero_nan drops from B depends on the reference's COLUMN-major sequence of B
+    (multiply_sparse.hpp:168, algorithm.hpp:272-275).  Small shapes against the FAITHFUL restatement
+    (inner-product loops, rowwise=False), all transposes and policies."""
+    from spsparse_amd import capi
+    A = orc.Mat([0, 0], [0, 1], [1., 1.], (1, 2))
+    B = orc.Mat([0, 1], [1, 0], [np.nan, 5.], (2, 2))
+    got = _dev(ctx, A, B, zero_nan=True, flags=capi.SINK_ORDERED)
+    assert got[0].tolist() == [0, 0] and got[1].tolist() == [0, 1] and got[2][0] == 5.0 and np.isnan(got[2][1])
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        m, k, n = rng.integers(1, 14, 3)
+        tA, tB = ".T"[trial % 2], ".T"[(trial // 2) % 2]
+        A = _rand_mat(rng, (k, m) if tA == "T" else (m, k), int(rng.integers(1, 80)), zeros=True)
+        B = _rand_mat(rng, (n, k) if tB == "T" else (k, n), int(rng.integers(1, 80)), zeros=True)
+        for M in (A, B):
+            M.val[rng.integers(0, M.val.size, max(1, M.val.size // 4))] = np.nan
+        dup = [capi.ADD, capi.LEAVE_ALONE, capi.REPLACE][trial % 3]
+        for zn in (False, True):
+            want = orc.multiply(A, B, 1.0, None, tA, None, tB, None, dup, zero_nan=zn)          # faithful loops
+            got = _dev(ctx, A, B, tA=tA, tB=tB, duplicate_policy=dup, zero_nan=zn, flags=capi.SINK_ORDERED)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.array_equal(got[2], want[2], equal_nan=True)
+        if trial % 4 == 0:                                       # the same matrix on both sides, row-major = A's order
+            S = _rand_mat(rng, (9, 9), 40, zeros=True)
+            S.val[rng.integers(0, S.val.size, 8)] = np.nan
+            want = orc.multiply(S, S, zero_nan=True)
+            got = _dev(ctx, S, S, zero_nan=True, flags=capi.SINK_ORDERED)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.array_equal(got[2], want[2], equal_nan=True)
+
+
 def test_bench_dist_path_matches_plain_path():
     """bench.py's N>1 code (row block, calibration rounds, all-to-allv of B panels over RCCL, digest
     reduction) rehearsed on a 1-rank NCCL group: same digest as the plain single-GPU path."""
@@ -397,17 +429,37 @@ def test_two_contexts_on_two_threads(ctx):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("dbg", [0, 1024, 1536])
-def test_coo_emission_paths_agree(ctx, dbg, monkeypatch):
+def test_ablation_switch_is_not_in_the_shipped_library(monkeypatch):
+    """SPSAMD_DBG (ablations that skip work and give wrong results on purpose) exists only in
+    -DSPSAMD_ABLATIONS profiling builds.  With it set in the environment a fresh context still
+    returns the oracle's product."""
+    from spsparse_amd import capi
+    monkeypatch.setenv("SPSAMD_DBG", "31")
+    c = capi.Context()
+    try:
+        a = wl.rmat(12, seed=5)
+        A = orc.Mat(*a)
+        want = orc.multiply(A, A, rowwise=True, nthreads=8)
+        got = _dev(c, A, A)
+        _check(got, want)
+        assert got[3].cells_hash > 0 and got[3].cells_dense > 0
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("path", [0, 1, 2])
+def test_coo_emission_paths_agree(ctx, path):
     """The three ways a hash cell is emitted in column order -- bitmap rank (narrow cells), LDS radix
-    sort, bitonic network (keys wider than 32 bits) -- forced in turn through the developer switch:
-    the same tuples in the same order, against the oracle.  (dbg only selects the path.)"""
+    sort, bitonic network (keys wider than 32 bits) -- forced in turn through the tuning knob:
+    the same tuples in the same order, against the oracle."""
     a = wl.rmat(15, seed=2)
     A = orc.Mat(*a)
     want = orc.multiply(A, A, rowwise=True, nthreads=8)
-    monkeypatch.setenv("SPSAMD_DBG", str(dbg))
-    got = _dev(ctx, A, A)
-    monkeypatch.delenv("SPSAMD_DBG")
+    ctx.set_tuning("emit_path", path)
+    try:
+        got = _dev(ctx, A, A)
+    finally:
+        ctx.set_tuning("emit_path", 0)
     _check(got, want)
     assert got[3].cells_hash > 0 and got[3].rows_mid > 0
 
@@ -823,7 +875,6 @@ def test_cfg3_poisson4096_full_size_properties(ctx):
 def test_cfg5_galerkin256_full_size_properties(ctx):
     """BASELINE cfg5: R*A*R^T on the 256^3 Laplacian; closed forms nnz(T)=32nc^3-24nc^2,
     nnz(C)=7nc^3-6nc^2 and the value set {24,-4} (every entry an integer: exact)."""
-    import torch
     from spsparse_amd import capi
     N, nc = 256, 128
     A, k1 = _device_operand(ctx, lambda *p: ctx.gen_laplace3d(N, *p), 7 * N ** 3 - 6 * N ** 2, (N ** 3, N ** 3), sort0=0)
@@ -831,17 +882,49 @@ def test_cfg5_galerkin256_full_size_properties(ctx):
     rt = ctx.multiply(R, A, sink=capi.SINK_COO)
     nt = int(rt.nnz)
     assert nt == 32 * nc ** 3 - 24 * nc ** 2 and rt.products == 7 * N ** 3 - 6 * N ** 2
-    dev = torch.device("cuda:0")
-    t = (torch.empty(nt, dtype=torch.int32, device=dev), torch.empty(nt, dtype=torch.int32, device=dev),
-         torch.empty(nt, dtype=torch.float64, device=dev))
-    ctx.memcpy(t[0].data_ptr(), rt.idx0, nt * 4)
-    ctx.memcpy(t[1].data_ptr(), rt.idx1, nt * 4)
-    ctx.memcpy(t[2].data_ptr(), rt.val, nt * 8)
-    T = capi.device_coo(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), nt, (nc ** 3, N ** 3), sort0=0)
+    # T is chained as it stands: the result buffers are the operand of the next call (no copy, no
+    # re-consolidation), whose own result goes to the context's other output buffer
+    T = capi.result_operand(rt)
     rc = ctx.multiply(T, R, tB="T", sink=capi.SINK_COO)
+    assert rc.idx0 != rt.idx0 and rc.val != rt.val
+    assert rc.ms_consolidate < 5.0                          # T (66.7M tuples) was inspected, not sorted
     assert rc.nnz == 7 * nc ** 3 - 6 * nc ** 2 and rc.products == nt
     vals = np.unique(ctx.to_host(rc.val, int(rc.nnz), np.float64))
     assert vals.tolist() == [-4.0, 24.0]
     ci = ctx.to_host(rc.idx0, int(rc.nnz), np.int32).astype(np.int64)
     cj = ctx.to_host(rc.idx1, int(rc.nnz), np.int32)
     assert np.all(np.diff(ci * nc ** 3 + cj) > 0)         # ascending (i, j), each once
+
+
+def test_cfg4_rmat23_single_gpu_properties(ctx):
+    """BASELINE cfg4 on ONE GPU ("the same input must also run on 1 GPU"): R-MAT scale-23
+    A*A, 134M raw tuples, P ~ 3.7e11, digest + row statistics.  Too large for the oracle: every row
+    sum and the grand sum follow from linearity ((A A) 1 = A (A 1), duplicates included), the product
+    count from the consolidated operand, and the 16384-column window path is the one taken."""
+    import torch
+    from spsparse_amd import capi
+    scale, seed = 23, 1
+    n, ne = 1 << scale, 16 << scale
+    A, keep = _device_operand(ctx, lambda *p: ctx.gen_rmat(scale, seed, 0, ne, *p), ne, (n, n))
+    d = ctx.multiply(A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    assert d.window == 16384 and d.rows_heavy > 0 and d.cells_dense > 0 and d.cells_hash > 0
+    # host side of the check: the raw tuples (the device generator is bit-identical to workloads.rmat,
+    # test_device_generators_match_numpy) copied out instead of regenerated
+    a0, a1, av = keep[0].cpu().numpy(), keep[1].cpu().numpy(), keep[2].cpu().numpy()
+    b1 = np.bincount(a0, weights=av, minlength=n)
+    want = np.bincount(a0, weights=av * b1[a1], minlength=n)
+    got = ctx.to_host(d.row_sum, n, np.float64)
+    nz = want != 0
+    assert np.array_equal(got != 0, nz)
+    assert np.max(np.abs(got[nz] - want[nz]) / want[nz]) <= 1e-10
+    assert abs(d.sum - want.sum()) <= 1e-10 * want.sum()
+    rn = ctx.to_host(d.row_nnz, n, np.int64)
+    assert int(rn.sum()) == d.nnz and d.nnz <= d.products
+    # products and nnz(A) from the distinct (row, col) pairs
+    key = np.unique(a0.astype(np.int64) * n + a1)
+    rowlen = np.bincount((key // n).astype(np.int64), minlength=n)
+    assert d.nnz_a == key.size == d.nnz_b
+    assert d.products == int(rowlen[(key % n).astype(np.int64)].sum())
+    assert 1.0e11 < d.nnz < d.products and 3.0e11 < d.products < 4.5e11
+    del keep
+    torch.cuda.empty_cache()

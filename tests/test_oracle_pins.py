@@ -230,6 +230,33 @@ def test_rowwise_equals_innerproduct_bitwise(tA, tB):
             assert np.array_equal(x[2], y[2])
 
 
+def test_rowwise_equals_innerproduct_with_nan_and_zero_nan():
+    """zero_nan drops the NaNs of the LEADING run of consolidate's own sorted sequence only
+    (algorithm.hpp:272-275 vs :284-292), and B's sequence is column-major (multiply_sparse.hpp:168):
+    the row-wise checker must consolidate B in that order before re-sorting it.  Includes the
+    two-tuple case where a row-major reading of B drops the wrong NaN."""
+    A = orc.Mat([0, 0], [0, 1], [1., 1.], (1, 2))
+    B = orc.Mat([0, 1], [1, 0], [np.nan, 5.], (2, 2))
+    a = orc.multiply(A, B, zero_nan=True)
+    b = orc.multiply(A, B, zero_nan=True, rowwise=True)
+    assert a[0].tolist() == b[0].tolist() == [0, 0] and a[1].tolist() == b[1].tolist() == [0, 1]
+    assert a[2][0] == b[2][0] == 5.0 and np.isnan(a[2][1]) and np.isnan(b[2][1])
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        m, k, n = rng.integers(1, 12, 3)
+        tA, tB = ".T"[trial % 2], ".T"[(trial // 2) % 2]
+        A = _rand_mat(rng, (k, m) if tA == "T" else (m, k), int(rng.integers(1, 60)), zeros=True)
+        B = _rand_mat(rng, (n, k) if tB == "T" else (k, n), int(rng.integers(1, 60)), zeros=True)
+        for M in (A, B):
+            M.val[rng.integers(0, M.val.size, max(1, M.val.size // 4))] = np.nan
+        dup = [orc.ADD, orc.LEAVE_ALONE, orc.REPLACE][trial % 3]
+        for zn in (False, True):
+            x = orc.multiply(A, B, 1.0, None, tA, None, tB, None, dup, zero_nan=zn)
+            y = orc.multiply(A, B, 1.0, None, tA, None, tB, None, dup, zero_nan=zn, rowwise=True)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+            assert np.array_equal(x[2], y[2], equal_nan=True)
+
+
 def test_ab_equals_btat_transposed():
     """multiply_sparse.hpp:15-18 doc example: AB == (B^T A^T)^T, bitwise."""
     rng = np.random.default_rng(3)
