@@ -1195,6 +1195,46 @@ __global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwi
 	}
 }
 
+// ---- window-major copy of B for the dense cells -------------------------------------------
+// A dense cell is one output row x ONE column window, and the cell lists are walked window by
+// window.  In the row-major array the tuples of window w are scattered over all of B (a few
+// tuples per 128-byte line belong to the window), and the index lookups bwin[k][w] touch one line
+// per B row.  The window-major copy puts the tuples of window w side by side, ordered by (k, col),
+// with a CSR row pointer per window: wptr[w * nrowb + k] .. [+1].  The working set of the
+// workgroups that are on window w is then |B_w| * 12 bytes plus a 4 * nrowb byte pointer slice,
+// and a row's pass over its A tuples (ascending k) moves forward through both.
+__global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_t nrowb, uint32_t nwin, uint32_t nwin1, uint32_t *cnt)
+{
+	__shared__ uint32_t tile[64][65];
+	const uint32_t k0 = blockIdx.x * 64u, w0 = blockIdx.y * 64u;
+	const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+	for (uint32_t ky = ty; ky < 64; ky += 4) {
+		const uint32_t k = k0 + ky;
+		if (k < nrowb) {
+			const uint32_t *row = bwin + (uint64_t)k * nwin1;
+			if (w0 + tx < nwin1) tile[ky][tx] = row[w0 + tx];
+			if (tx == 0 && w0 + 64 < nwin1) tile[ky][64] = row[w0 + 64];
+		}
+	}
+	__syncthreads();
+	for (uint32_t wy = ty; wy < 64; wy += 4) {
+		const uint32_t w = w0 + wy, k = k0 + tx;
+		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = tile[tx][wy + 1] - tile[tx][wy];
+	}
+}
+
+__global__ void k_wm_scatter(const int32_t *brow, const int32_t *bcol, const double *bval, uint32_t nnzb, uint32_t wshift,
+	const uint32_t *bwin, uint32_t nwin1, const uint32_t *wptr, uint64_t nrowb, BTup *out)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= nnzb) return;
+	const uint32_t k = (uint32_t)brow[e], c = (uint32_t)bcol[e], w = c >> wshift;
+	const uint32_t dst = wptr[(uint64_t)w * nrowb + k] + (e - bwin[(uint64_t)k * nwin1 + w]);
+	const double v = bval[e];
+	BTup t; t.col = (int32_t)c; t.vlo = (uint32_t)__double2loint(v); t.vhi = (uint32_t)__double2hiint(v);
+	out[dst] = t;
+}
+
 // Per heavy row: products per column window.  One workgroup per row; a thread owns a PAIR of
 // windows (one 32-bit load per A tuple), sub-groups of threads take different tuples and every
 // thread keeps 8 tuples in flight.  A row's workgroup takes at most WH_HUB tuples; rows with more
@@ -1418,7 +1458,7 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 // more products than a hash cell takes) with a grid stride.
 template <int W, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
-	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
+	const uint32_t *widx, uint64_t kstride, uint64_t wstride, EmitParams ep, SinkParams sk)
 {
 	constexpr int NW = NT / 64;
 	constexpr int NGRP = W / 64;             // 64-slot groups per window
@@ -1450,7 +1490,9 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		const uint32_t e = rec1.beg + tid;
 		const bool act = e < rec1.end;
 		const uint32_t ec = act ? e : rec1.beg;
-		const uint32_t *bw = bwin + (uint64_t)m.acol[ec] * nwin1 + rec1.wa;
+		// segment of B row k in window w: [widx[k*kstride + w*wstride], widx[.. + 1]) -- the row-major index
+		// bwin (kstride = nwin+1, wstride = 1) or the window-major row pointer wptr (kstride = 1, wstride = nrowb)
+		const uint32_t *bw = widx + (uint64_t)(uint32_t)m.acol[ec] * kstride + (uint64_t)rec1.wa * wstride;
 		const uint32_t lo = bw[0], hi = bw[1];
 		na = m.aval[ec];
 		nlo = lo; nlen = act ? hi - lo : 0u;
@@ -1479,7 +1521,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 				lo = 0; len = 0; a = 0;
 				if (e < end) {
 					int32_t k = m.acol[e];
-					const uint32_t *bw = bwin + (uint64_t)k * nwin1 + w;
+					const uint32_t *bw = widx + (uint64_t)(uint32_t)k * kstride + (uint64_t)w * wstride;
 					lo = bw[0]; len = bw[1] - lo;
 					a = m.aval[e];
 				}
@@ -1552,7 +1594,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		}
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
 		{
-			const uint32_t *bw = bwin + (uint64_t)nk * nwin1 + rec1.wa;
+			const uint32_t *bw = widx + (uint64_t)(uint32_t)nk * kstride + (uint64_t)rec1.wa * wstride;
 			const uint32_t lo = bw[0], hi = bw[1];
 			nlo = lo; nlen = nact ? hi - lo : 0u;
 		}
@@ -1711,6 +1753,9 @@ struct Heavy {
 	uint32_t ntile = 0, ntcell = 0;
 	bool coo = false;                // the tiles also serve a STORE launch
 	unsigned long long clsprod[NCLS] = {};
+	uint32_t *wptr = nullptr;        // window-major copy of B (dense cells): row pointer per window ...
+	BTup *btw = nullptr;             // ... and tuples
+	uint64_t nrowb = 0;
 };
 
 template <int MODE>
@@ -1734,18 +1779,37 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 }
 
 template <int MODE>
-static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
+static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const EmitParams &ep, const SinkParams &sk)
 {
 	if (!hv.ncell[CLS_DENSE]) return;
+	RowMeta m = m0;
+	const uint32_t *widx = hv.bwin;
+	uint64_t kstride = hv.nwin1, wstride = 1;
+	if (hv.wptr) { widx = hv.wptr; kstride = 1; wstride = hv.nrowb; m.btup = hv.btw; }
 	if (hv.W == 8192) {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, hv.bwin, hv.nwin1, ep, sk);
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, ep, sk);
 	} else {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, hv.bwin, hv.nwin1, ep, sk);
+		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, ep, sk);
 	}
+	SPS_LAUNCH_CHECK();
+}
+
+// Window-major copy of B (see k_wm_counts): built once the cell grouping has shown that dense cells exist.
+static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift)
+{
+	hipStream_t st = c->stream;
+	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
+	uint32_t *cnt = c->arena.get<uint32_t>(total);
+	hv.wptr = c->arena.get<uint32_t>(total + 1);
+	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(hv.bwin, (uint32_t)nrowb, hv.nwin, hv.nwin1, cnt);
+	SPS_LAUNCH_CHECK();
+	scan_exclusive_u32_u32(c, cnt, hv.wptr, total);
+	hv.btw = c->arena.get<BTup>(B.nnz);
+	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
 	SPS_LAUNCH_CHECK();
 }
 
@@ -1768,6 +1832,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	if (hv.nwin > (uint32_t)WH_MAXW) throw Error{SPSAMD_EINVAL, "too many column windows (ncol > 2^25) for the heavy-row path"};
 	hv.nwin1 = hv.nwin + 1;
 	const uint64_t nrowb = B.nrow + extra;
+	hv.nrowb = nrowb;
 	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
 	k_bwin_prefill<<<dim3(4096), dim3(256), 0, st>>>(bptr, nrowb, hv.nwin1, hv.bwin);
 	SPS_LAUNCH_CHECK();
@@ -1809,6 +1874,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	hv.ntcell = read_back(c, hv.tb.tcbase + hv.n);
 	hv.ntile = read_back(c, hv.tb.tlbase + hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
+	if (hv.ncell[CLS_DENSE] && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
 }
 
 // Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.

@@ -442,7 +442,7 @@ def test_ablation_switch_is_not_in_the_shipped_library(monkeypatch):
         want = orc.multiply(A, A, rowwise=True, nthreads=8)
         got = _dev(c, A, A)
         _check(got, want)
-        assert got[3].cells_hash > 0 and got[3].cells_dense > 0
+        assert got[3].rows_heavy > 0 and got[3].cells_dense > 0        # the kernels that carried the switches ran
     finally:
         c.close()
 
