@@ -12,7 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+# developer experiments: SPSAMD_VARIANT=name builds lib/name/libspsparse_amd.so with SPSAMD_CXXFLAGS (capi.py loads it
+# when SPSAMD_LIB points there); the shipped library is the one without a variant
+VARIANT = os.environ.get("SPSAMD_VARIANT", "")
+LIBDIR = os.path.join(HERE, "lib", VARIANT) if VARIANT else os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspsparse_amd.so")
 SOURCES = ["prims.hip", "consolidate.hip", "spgemm.hip", "workload.hip", "capi.hip"]
 HEADERS = ["internal.h", "devutil.h", "workload_common.h", os.path.join("..", "..", "include", "spsparse_amd.h")]

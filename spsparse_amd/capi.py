@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspsparse_amd.so")
+LIB_PATH = os.environ.get("SPSAMD_LIB") or os.path.join(_HERE, "lib", "libspsparse_amd.so")    # SPSAMD_LIB: a developer variant build
 
 LEAVE_ALONE, ADD, REPLACE = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -531,6 +531,84 @@ __device__ __forceinline__ uint32_t expand_lookup(const Expand<NT, PB> &L, uint3
 }
 
 
+// ---- the same flattening in units of ITEMS of R consecutive B tuples (dense cells) ----------
+// A segment of `len` tuples is ceil(len / R) items; an item never crosses a segment, so ONE lookup
+// (item -> segment) serves R products: the lane then reads its R tuples as one contiguous 12 R-byte
+// piece and masks the tail of the segment's last item.  Padding costs one partial item per segment
+// (dense cells average 27 tuples per non-empty segment); the lookup's LDS reads and popcount
+// arithmetic, which co-limit the loop with the LDS accumulate, are paid once per R products.
+#ifndef DENSE_R_V
+#define DENSE_R_V 4
+#endif
+constexpr int DENSE_R = DENSE_R_V;
+
+template <int NT, int PB>
+struct ExpandR {
+	uint32_t cpref[NT + 1];          // compacted segments: exclusive ITEM prefix (+ total)
+	uint2 cse[NT];                   // first tuple of the segment, one past its last
+	double caval[NT];                // the A value
+	unsigned long long bmask[PB / 64];
+	uint32_t bq[PB / 64];
+	uint32_t scrL[2][NT / 64], scrN[2][NT / 64];
+};
+
+template <int NT, int PB>
+__device__ __forceinline__ void expandr_load(ExpandR<NT, PB> &L, uint32_t lo, uint32_t len, double a, uint32_t *total, uint32_t *nzc,
+	uint32_t &flip)
+{
+	constexpr int NW = NT / 64;
+	const uint32_t items = (len + DENSE_R - 1) / DENSE_R;
+	const uint32_t inc = wave_inclusive_scan_u32(items);
+	const uint64_t nzm = __ballot(len != 0);
+	const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
+	if (lane_id() == 63) L.scrL[flip][wave_id()] = inc;
+	if (lane_id() == 0) L.scrN[flip][wave_id()] = (uint32_t)__popcll(nzm);
+	lds_barrier();
+	uint32_t baseL = 0, baseN = 0, totL = 0, totN = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		uint32_t l = L.scrL[flip][w], n = L.scrN[flip][w];
+		if (w < (int)wave_id()) { baseL += l; baseN += n; }
+		totL += l; totN += n;
+	}
+	flip ^= 1u;
+	if (len) {
+		uint32_t rank = baseN + wrank;
+		L.cpref[rank] = baseL + inc - items;
+		L.cse[rank] = make_uint2(lo, lo + len);
+		L.caval[rank] = a;
+	}
+	if (threadIdx.x == 0) L.cpref[totN] = totL;
+	*total = totL;
+	*nzc = totN;
+}
+
+// Lookup tables for items [pb, pe), pe - pb <= PB.  Two barriers.
+template <int NT, int PB>
+__device__ __forceinline__ void expandr_batch(ExpandR<NT, PB> &L, uint32_t pb, uint32_t pe, uint32_t nzc)
+{
+	const uint32_t nblk = (pe - pb + 63) >> 6;
+	for (uint32_t b = threadIdx.x; b < nblk; b += NT) L.bmask[b] = 0;
+	lds_barrier();
+	for (uint32_t b = threadIdx.x; b < nblk; b += NT) {
+		uint32_t p = pb + (b << 6), lo = 0, hi = nzc - 1;
+		while (hi > lo) {
+			uint32_t mid = (lo + hi + 1) >> 1;
+			if (L.cpref[mid] <= p) lo = mid; else hi = mid - 1;
+		}
+		L.bq[b] = lo;
+	}
+	for (uint32_t i = threadIdx.x; i < nzc; i += NT) {
+		uint32_t s = L.cpref[i];
+		if (s > pb && s < pe && ((s - pb) & 63u)) atomicOr(&L.bmask[(s - pb) >> 6], 1ull << ((s - pb) & 63u));
+	}
+	lds_barrier();
+}
+
+// R consecutive B tuples as the loop reads them: 12 R bytes at a 4-byte aligned address.
+struct __attribute__((packed, aligned(4))) BPiece { uint32_t w[3 * DENSE_R]; };
+
+
 // XCD-aware walk of a cell list.  Workgroups are dispatched round-robin over the 8 XCDs
 // (blockIdx % 8 names the group of blocks that share an XCD and its L2).  The list, which is
 // in window-major order, is cut into 8 contiguous parts of equal cost (xb[0..8]); XCD group
@@ -1454,8 +1532,18 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 
 // ====================================================================== dense cells (f64 window accumulator in LDS)
 
-// Persistent workgroups walk the dense cells (one window of one row holding
-// more products than a hash cell takes) with a grid stride.
+// Persistent workgroups walk the dense cells (one window of one row holding more products than a
+// hash cell takes) with a grid stride.
+//
+// Product loop.  A chunk of NT A tuples selects NT segments of B (one window each).  A non-empty
+// segment of `len` tuples is ceil(len / R) ITEMS of R consecutive tuples; items are numbered
+// 0..total-1 over the compacted segments and dealt 64 consecutive items per wave and step.  The
+// segment of an item needs no search: every segment sets the bit of its first item in a bitmap
+// (one 64-bit word per 64-item block), each wave keeps the words and their popcount prefix in
+// registers (word l and l + 64 in lane l), and for block b -- wave-uniform -- takes both with
+// v_readlane; a lane's segment is then  prefix + (bits of the word up to its own position) - 1.
+// One LDS round trip (segment bounds, item prefix, A value) per R products follows, the R tuples
+// are read as one 12 R-byte piece, and the sums go to the LDS accumulator with ds_add_f64.
 template <int W, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *widx, uint64_t kstride, uint64_t wstride, EmitParams ep, SinkParams sk)
@@ -1464,21 +1552,32 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 	constexpr int NGRP = W / 64;             // 64-slot groups per window
 	constexpr int GPW = NGRP / NW;           // groups per wave
 	constexpr uint32_t WSHIFT = W == 8192 ? 13 : 14;
+	constexpr int R = DENSE_R;
+	constexpr int NWORD = W / 64;            // bitmap words of one batch (W items)
+	constexpr int WPL = NWORD / 64;          // words per lane of the per-wave copy
 	__shared__ double acc[W];
-	__shared__ Expand<NT, W> X;
+	__shared__ uint32_t s_cpref[NT + 1];     // compacted segments: exclusive ITEM prefix (+ total)
+	__shared__ uint2 s_cse[NT];              // first tuple of the segment, one past its last
+	__shared__ double s_caval[NT];           // the A value
+	__shared__ unsigned long long s_bmask[NWORD];
+	__shared__ uint32_t s_scrL[2][NW], s_scrN[2][NW];
 	__shared__ uint32_t s_wcnt[NW + 1];
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
 
-	const unsigned tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+	const unsigned tid = threadIdx.x, lane = lane_id();
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
 	for (int q = tid; q < W; q += NT) acc[q] = 0.0;
+	for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
 	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
 	uint32_t flip = 0;
 
 	// Cells are ordered by (window, descending products) and dealt with a grid stride, so the
-	// workgroups are on the same few column windows of B at any time (B's window slice is served
-	// from L2 / Infinity Cache) and every workgroup gets a mix of large and small cells.
-	// Same three-stage software pipeline as k_hash.
+	// workgroups are on the same few column windows of B at any time and every workgroup gets a
+	// mix of large and small cells.  Software pipeline over the cells: the record of cell i+2, the
+	// A tuples of cell i+1 and then its B segment bounds are loaded while cell i is processed
+	// (branch-free prefetches: indices clamped, results masked); inside a cell the A tuples of
+	// chunk c+2 and the segment bounds of chunk c+1 are in flight while chunk c is processed.
 	const CellWalk walk = cell_walk(xb, ncell);
 	const uint32_t stride = walk.stride, cend = walk.end;
 	const bool any_cell = walk.first < cend;
@@ -1486,17 +1585,22 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 	Cell rec1 = cells[min(walk.first, clast)];
 	Cell rec2 = cells[min(walk.first + stride, clast)];
 	uint32_t nlo, nlen; double na;
+	auto seg_bounds = [&](int32_t k, uint32_t w, uint32_t &lo, uint32_t &hi) {
+		// segment of B row k in window w: [widx[k*kstride + w*wstride], widx[.. + 1]) -- the row-major index
+		// bwin (kstride = nwin+1, wstride = 1) or the window-major row pointer wptr (kstride = 1, wstride = nrowb)
+		const uint32_t *bw = widx + (uint64_t)(uint32_t)k * kstride + (uint64_t)w * wstride;
+		lo = bw[0]; hi = bw[1];
+	};
 	{
 		const uint32_t e = rec1.beg + tid;
 		const bool act = e < rec1.end;
 		const uint32_t ec = act ? e : rec1.beg;
-		// segment of B row k in window w: [widx[k*kstride + w*wstride], widx[.. + 1]) -- the row-major index
-		// bwin (kstride = nwin+1, wstride = 1) or the window-major row pointer wptr (kstride = 1, wstride = nrowb)
-		const uint32_t *bw = widx + (uint64_t)(uint32_t)m.acol[ec] * kstride + (uint64_t)rec1.wa * wstride;
-		const uint32_t lo = bw[0], hi = bw[1];
+		uint32_t lo, hi;
+		seg_bounds(m.acol[ec], rec1.wa, lo, hi);
 		na = m.aval[ec];
 		nlo = lo; nlen = act ? hi - lo : 0u;
 	}
+	__syncthreads();
 	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
 		const Cell cell = rec1;
 		const uint32_t w = cell.wa;
@@ -1504,7 +1608,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		const int32_t rowid = cell.rowid;
 		const double a_scale = row_scale(ep, rowid);
 		const uint32_t wbase = w << WSHIFT;
-		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
+		uint32_t lo = nlo, len = nlen; double a = na;               // chunk 0, prefetched
 		rec1 = rec2;
 		rec2 = cells[min(ci + 2 * stride, clast)];
 		const uint32_t ne = rec1.beg + tid;
@@ -1512,94 +1616,149 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
-		lds_barrier();                                              // previous cell's scan-out complete
+		// in-cell prefetch, stage A: the A tuple of chunk 1
+		int32_t kA = 0; double aA = 0.0;
+		if (beg + NT < end) {                                       // uniform
+			const uint32_t e1 = beg + NT + tid;
+			const uint32_t e1c = e1 < end ? e1 : beg;
+			kA = m.acol[e1c]; aA = m.aval[e1c];
+		}
 
 		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
-			uint32_t lo = lo0, len = len0; double a = a0;
-			if (chunk != beg) {
-				uint32_t e = chunk + tid;
-				lo = 0; len = 0; a = 0;
-				if (e < end) {
-					int32_t k = m.acol[e];
-					const uint32_t *bw = widx + (uint64_t)(uint32_t)k * kstride + (uint64_t)w * wstride;
-					lo = bw[0]; len = bw[1] - lo;
-					a = m.aval[e];
+			// stage B for chunk c+1 (its k arrived during chunk c-1), stage A for chunk c+2
+			uint32_t lo2 = 0, hi2 = 0; double a2 = 0.0;
+			if (chunk + NT < end) {                                 // uniform
+				seg_bounds(kA, w, lo2, hi2);
+				a2 = aA;
+				if (chunk + NT + tid >= end) hi2 = lo2;
+				if (chunk + 2 * NT < end) {
+					const uint32_t e2 = chunk + 2 * NT + tid;
+					const uint32_t e2c = e2 < end ? e2 : beg;
+					kA = m.acol[e2c]; aA = m.aval[e2c];
 				}
 			}
-			uint32_t total, nzc, ex;
-			expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
-			if (total == 0) continue;                               // uniform
+			// ---- compact the non-empty segments, item prefix, first-item bits
+			const uint32_t items = (len + R - 1) / R;
+			const uint32_t inc = wave_inclusive_scan_u32(items);
+			const uint64_t nzm = __ballot(len != 0);
+			const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
+			if (lane == 63) s_scrL[flip][wv] = inc;
+			if (lane == 0) s_scrN[flip][wv] = (uint32_t)__popcll(nzm);
+			lds_barrier();                                          // B1: also orders the previous chunk's / cell's LDS traffic
+			uint32_t baseL = 0, baseN = 0, total = 0, nzc = 0;
+#pragma unroll
+			for (int q = 0; q < NW; ++q) {
+				const uint32_t l = s_scrL[flip][q], n = s_scrN[flip][q];
+				if (q < (int)wv) { baseL += l; baseN += n; }
+				total += l; nzc += n;
+			}
+			flip ^= 1u;
+			const uint32_t myfirst = baseL + inc - items;           // first item of this thread's segment
+			if (len) {
+				const uint32_t rank = baseN + wrank;
+				s_cpref[rank] = myfirst;
+				s_cse[rank] = make_uint2(lo, lo + len);
+				s_caval[rank] = a;
+				if (myfirst < (uint32_t)W) atomicOr(&s_bmask[myfirst >> 6], 1ull << (myfirst & 63u));
+			}
 			if (ABL(ep, 8)) total = 0;
+			if (total == 0) { lo = lo2; len = hi2 - lo2; a = a2; continue; }     // uniform (nothing was marked)
 			if (ep.ordered && MODE != MODE_COUNT) {
 				// ascending-k accumulation, one segment (unique columns) at a time: see hash_products_ordered
-				lds_barrier();                                      // the compacted segments are visible
+				lds_barrier();
 				for (uint32_t q = 0; q < nzc; ++q) {
-					const uint32_t len_q = X.cpref[q + 1] - X.cpref[q], start = X.cstart[q];
-					const double aq = X.caval[q];
-					for (uint32_t t = tid; t < len_q; t += NT) {
-						const BTup bt = m.btup[start + t];
+					const uint2 se = s_cse[q];
+					const double aq = s_caval[q];
+					for (uint32_t t = se.x + tid; t < se.y; t += NT) {
+						const BTup bt = m.btup[t];
 						const uint32_t slot = (uint32_t)bt.col - wbase;
 						acc[slot] = acc[slot] + aq * btup_val(bt);
 					}
 					lds_barrier();
 				}
+				for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
+				lo = lo2; len = hi2 - lo2; a = a2;
 				continue;
 			}
-			// products of the chunk in batches of W
+			uint32_t Q0 = 0;                                        // segments that start before the batch
 			for (uint32_t pb = 0; pb < total; pb += W) {
 				const uint32_t pe = min(total, pb + (uint32_t)W);
-				expand_batch(X, pb, pe, nzc);
-				// U products per thread and step: all B loads of a step are issued before the first
-				// is used (the loop is bound by load latency, not by bandwidth or issue rate).
-				// A thread past the end re-reads the last product with weight 0.
-				// Software pipelined over the steps: the segment lookups of step s+1 (two dependent LDS
-				// round trips) are issued while the B loads of step s are in flight, so a step costs
-				// max(lookup, gather) + accumulate instead of their sum.
-				constexpr int U = DENSE_U;
-				const uint32_t nsteps = (pe - pb + NT * U - 1) / (NT * U);      // uniform
-				uint32_t bp[U]; double av[U];
-				auto lookup = [&](uint32_t step, uint32_t (&obp)[U], double (&oav)[U]) {
-#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						uint32_t p = pb + step * (NT * U) + u * NT + tid;
-						const bool ok = p < pe;
-						p = ok ? p : pe - 1;
-						uint32_t q = expand_lookup(X, p, pb);
-						obp[u] = X.cstart[q] + (p - X.cpref[q]);
-						oav[u] = ok ? X.caval[q] : 0.0;
-					}
-				};
-				lookup(0, bp, av);
-				for (uint32_t step = 0; step < nsteps; ++step) {
-					uint32_t col[U]; double bv[U];
-#pragma unroll
-					for (int u = 0; u < U; ++u) { const BTup t = m.btup[bp[u]]; col[u] = (uint32_t)t.col; bv[u] = btup_val(t); }
-					uint32_t nbp[U]; double nav[U];
-					if (step + 1 < nsteps) lookup(step + 1, nbp, nav);          // uniform branch
-					else {
-#pragma unroll
-						for (int u = 0; u < U; ++u) { nbp[u] = bp[u]; nav[u] = 0.0; }
-					}
-#pragma unroll
-					for (int u = 0; u < U; ++u) {
-						uint32_t slot = col[u] - wbase;
-						if (MODE == MODE_COUNT) acc[slot] = 1.0;    // structural: touched
-						else atomicAdd(&acc[slot], av[u] * bv[u]);
-					}
-#pragma unroll
-					for (int u = 0; u < U; ++u) { bp[u] = nbp[u]; av[u] = nav[u]; }
+				if (pb) {
+					// a later batch of a very large chunk: re-mark the first-item bits of its own range
+					lds_barrier();
+					for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
+					lds_barrier();
+					if (len && myfirst >= pb && myfirst < pe) atomicOr(&s_bmask[(myfirst - pb) >> 6], 1ull << ((myfirst - pb) & 63u));
 				}
-				lds_barrier();
+				lds_barrier();                                      // B2: compacted segments and bits visible
+				// ---- per-wave copy of the bitmap and its popcount prefix
+				unsigned long long mw[WPL]; uint32_t pre[WPL];
+				uint32_t run = Q0;
+#pragma unroll
+				for (int x = 0; x < WPL; ++x) {
+					mw[x] = s_bmask[x * 64 + lane];
+					const uint32_t cnt = (uint32_t)__popcll(mw[x]);
+					const uint32_t incl = wave_inclusive_scan_u32(cnt);
+					pre[x] = run + incl - cnt;
+					run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				}
+				const uint32_t nsteps = (pe - pb + NT - 1) / NT;            // uniform
+				auto lookup = [&](uint32_t step, uint32_t &obp, uint32_t &onv, double &oav) {
+					const uint32_t b = step * NW + wv;                       // wave-uniform block
+					const uint32_t t = pb + (b << 6) + lane;
+					const bool ok = t < pe;
+					uint32_t mlo = 0, mhi = 0, pr = 0;
+#pragma unroll
+					for (int x = 0; x < WPL; ++x) {
+						if ((b >> 6) == (uint32_t)x) {                       // uniform
+							mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mw[x], (int)(b & 63u));
+							mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mw[x] >> 32), (int)(b & 63u));
+							pr = (uint32_t)__builtin_amdgcn_readlane((int)pre[x], (int)(b & 63u));
+						}
+					}
+					if (ABL(ep, 128)) { obp = (t * R) & 0xFFFFFu; onv = ok ? R : 0u; oav = 1.0; return; }      // no segment lookup
+					const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+					uint32_t q = pr + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (uint32_t)((mask >> lane) & 1ull) - 1u;
+					q = min(q, nzc - 1u);                                    // lanes past the end of the last block
+					const uint2 se = s_cse[q];
+					obp = se.x + (t - s_cpref[q]) * R;
+					onv = ok ? min((uint32_t)R, se.y - obp) : 0u;
+					oav = s_caval[q];
+				};
+				uint32_t bp, nv; double av;
+				lookup(0, bp, nv, av);
+				const char *bbase = reinterpret_cast<const char *>(m.btup);
+				for (uint32_t step = 0; step < nsteps; ++step) {
+					const BPiece piece = *reinterpret_cast<const BPiece *>(bbase + (uint64_t)(ABL(ep, 64) ? (bp & 0xFFFFu) : bp) * 12u);
+					uint32_t nbp = bp, nnv = 0; double nav = 0.0;
+					if (step + 1 < nsteps) lookup(step + 1, nbp, nnv, nav);     // uniform branch
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						if ((uint32_t)u < nv) {
+							const uint32_t slot = ABL(ep, 64) ? (piece.w[3 * u] & (W - 1)) : piece.w[3 * u] - wbase;
+							if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[slot] = av; }         // no LDS accumulate
+							else if (MODE == MODE_COUNT) acc[slot] = 1.0;    // structural: touched
+							else atomicAdd(&acc[slot], av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
+						}
+					}
+					bp = nbp; nv = nnv; av = nav;
+				}
+				Q0 = run;
 			}
+			lds_barrier();                                          // B3: segment tables and bitmap are free again
+			for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
+			lo = lo2; len = hi2 - lo2; a = a2;
 		}
-		// stage C of the pipeline: B segment bounds of the next cell's first chunk
+		// stage C of the cell pipeline: B segment bounds of the next cell's first chunk (in flight during the scan-out)
 		{
-			const uint32_t *bw = widx + (uint64_t)(uint32_t)nk * kstride + (uint64_t)rec1.wa * wstride;
-			const uint32_t lo = bw[0], hi = bw[1];
-			nlo = lo; nlen = nact ? hi - lo : 0u;
+			uint32_t l2, h2;
+			seg_bounds(nk, rec1.wa, l2, h2);
+			nlo = l2; nlen = nact ? h2 - l2 : 0u;
 		}
 		if (ABL(ep, 16)) continue;
-		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns
+		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns.  (The last barrier of the
+		// chunk loop, B3, has every accumulate of this cell behind it; a cell with no product at all skips it and
+		// scans zeros, which is still ordered by the next cell's B1.)
 		double v[GPW];
 		uint64_t nzmask[GPW];
 		uint32_t wcount = 0;
@@ -1652,6 +1811,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 				}
 				if (tid == 0) sk.segactual[cell.seg] = wtotal;
 			}
+			__syncthreads();                                        // s_wcnt is reused by the next cell
 		}
 	}
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
@@ -1808,7 +1968,7 @@ static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32
 	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(hv.bwin, (uint32_t)nrowb, hv.nwin, hv.nwin1, cnt);
 	SPS_LAUNCH_CHECK();
 	scan_exclusive_u32_u32(c, cnt, hv.wptr, total);
-	hv.btw = c->arena.get<BTup>(B.nnz);
+	hv.btw = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);
 	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
 	SPS_LAUNCH_CHECK();
 }
@@ -2006,7 +2166,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->tuples_mid = hbc.tuples[5] + hbc.tuples[6] + hbc.tuples[7];
 	res->tuples_heavy = hbc.tuples[8];
 
-	BTup *btup = c->arena.get<BTup>(B.nnz);
+	BTup *btup = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);         // a dense-cell item reads R tuples: slack after the last one
 	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
 	SPS_LAUNCH_CHECK();
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
