@@ -31,7 +31,9 @@
 #include "devutil.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace spsamd {
 
@@ -81,7 +83,18 @@ struct SinkParams {
 	DigestSlot *digest;             // DIGEST_SLOTS accumulators
 	long long *row_nnz; double *row_sum;   // optional row statistics (DIGEST)
 	uint32_t *err;                  // device error word: a kernel that meets a state the host promised cannot occur sets a bit
+#ifdef SPSAMD_STAMPS
+	unsigned long long *stamps;     // diagnostic builds only: per-workgroup cycle counters of k_dense's phases
+#endif
 };
+
+#ifdef SPSAMD_STAMPS
+#define STAMP(i) do { const unsigned long long now_ = clock64(); st_[i] += now_ - st_t; st_t = now_; } while (0)
+#define STAMP_COUNT(i) (++st_[i])
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_COUNT(i) do { } while (0)
+#endif
 
 // One B tuple as the numeric kernels read it: column and value side by side (12 bytes), so
 // a short B segment sits in one or two cache lines instead of two partial lines of separate
@@ -539,6 +552,9 @@ __device__ __forceinline__ uint32_t expand_lookup(const Expand<NT, PB> &L, uint3
 // arithmetic, which co-limit the loop with the LDS accumulate, are paid once per R products.
 #ifndef DENSE_R_V
 #define DENSE_R_V 4
+#endif
+#ifndef DENSE_DEPTH
+#define DENSE_DEPTH 1
 #endif
 constexpr int DENSE_R = DENSE_R_V;
 
@@ -1544,9 +1560,11 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 // v_readlane; a lane's segment is then  prefix + (bits of the word up to its own position) - 1.
 // One LDS round trip (segment bounds, item prefix, A value) per R products follows, the R tuples
 // are read as one 12 R-byte piece, and the sums go to the LDS accumulator with ds_add_f64.
+// Occupancy: 16 waves per CU (two 512-thread workgroups, or one of 1024) = 4 per SIMD, so the kernel
+// is held to 128 VGPRs (launch bound 4): a build that needs more silently halves the occupancy.
 template <int W, int NT, int MODE>
-__global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
-	const uint32_t *widx, uint64_t kstride, uint64_t wstride, EmitParams ep, SinkParams sk)
+__global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
+	const uint32_t *widx, uint64_t kstride, uint64_t wstride, uint32_t narrow, EmitParams ep, SinkParams sk)
 {
 	constexpr int NW = NT / 64;
 	constexpr int NGRP = W / 64;             // 64-slot groups per window
@@ -1555,7 +1573,7 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 	constexpr int R = DENSE_R;
 	constexpr int NWORD = W / 64;            // bitmap words of one batch (W items)
 	constexpr int WPL = NWORD / 64;          // words per lane of the per-wave copy
-	__shared__ double acc[W];
+	__shared__ double acc[W + 64];           // + one dump slot per lane: tuples past the end of a segment's last item land there
 	__shared__ uint32_t s_cpref[NT + 1];     // compacted segments: exclusive ITEM prefix (+ total)
 	__shared__ uint2 s_cse[NT];              // first tuple of the segment, one past its last
 	__shared__ double s_caval[NT];           // the A value
@@ -1567,10 +1585,15 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 
 	const unsigned tid = threadIdx.x, lane = lane_id();
 	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
-	for (int q = tid; q < W; q += NT) acc[q] = 0.0;
+	for (int q = tid; q < W + 64; q += NT) acc[q] = 0.0;
 	for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
+	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;    // uniform: the emitted value is the sum itself
+	const unsigned long long laneK = (unsigned long long)lane * 0x9E3779B97F4A7C15ull;
 	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
 	uint32_t flip = 0;
+#ifdef SPSAMD_STAMPS
+	unsigned long long st_[12] = {}; unsigned long long st_t = clock64();
+#endif
 
 	// Cells are ordered by (window, descending products) and dealt with a grid stride, so the
 	// workgroups are on the same few column windows of B at any time and every workgroup gets a
@@ -1624,7 +1647,9 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			kA = m.acol[e1c]; aA = m.aval[e1c];
 		}
 
+		STAMP_COUNT(8);
 		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
+			STAMP_COUNT(9);
 			// stage B for chunk c+1 (its k arrived during chunk c-1), stage A for chunk c+2
 			uint32_t lo2 = 0, hi2 = 0; double a2 = 0.0;
 			if (chunk + NT < end) {                                 // uniform
@@ -1644,7 +1669,9 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
 			if (lane == 63) s_scrL[flip][wv] = inc;
 			if (lane == 0) s_scrN[flip][wv] = (uint32_t)__popcll(nzm);
+			STAMP(0);
 			lds_barrier();                                          // B1: also orders the previous chunk's / cell's LDS traffic
+			STAMP(1);
 			uint32_t baseL = 0, baseN = 0, total = 0, nzc = 0;
 #pragma unroll
 			for (int q = 0; q < NW; ++q) {
@@ -1653,6 +1680,8 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 				total += l; nzc += n;
 			}
 			flip ^= 1u;
+			total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);     // uniform by construction: keep the loop control scalar
+			nzc = (uint32_t)__builtin_amdgcn_readfirstlane((int)nzc);
 			const uint32_t myfirst = baseL + inc - items;           // first item of this thread's segment
 			if (len) {
 				const uint32_t rank = baseN + wrank;
@@ -1690,7 +1719,9 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 					lds_barrier();
 					if (len && myfirst >= pb && myfirst < pe) atomicOr(&s_bmask[(myfirst - pb) >> 6], 1ull << ((myfirst - pb) & 63u));
 				}
+				STAMP(2);
 				lds_barrier();                                      // B2: compacted segments and bits visible
+				STAMP(3);
 				// ---- per-wave copy of the bitmap and its popcount prefix
 				unsigned long long mw[WPL]; uint32_t pre[WPL];
 				uint32_t run = Q0;
@@ -1703,8 +1734,11 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 					run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 				}
 				const uint32_t nsteps = (pe - pb + NT - 1) / NT;            // uniform
+				// item -> (first tuple, valid tuples, A value).  Block b is wave-uniform: its bitmap word and prefix
+				// come out of the registers with v_readlane; the lane's segment is prefix + (first-item bits at
+				// positions <= lane) - 1, the bits below the lane counted by mbcnt on the word shifted right by one.
 				auto lookup = [&](uint32_t step, uint32_t &obp, uint32_t &onv, double &oav) {
-					const uint32_t b = step * NW + wv;                       // wave-uniform block
+					const uint32_t b = step * NW + wv;
 					const uint32_t t = pb + (b << 6) + lane;
 					const bool ok = t < pe;
 					uint32_t mlo = 0, mhi = 0, pr = 0;
@@ -1717,35 +1751,66 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 						}
 					}
 					if (ABL(ep, 128)) { obp = (t * R) & 0xFFFFFu; onv = ok ? R : 0u; oav = 1.0; return; }      // no segment lookup
-					const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
-					uint32_t q = pr + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (uint32_t)((mask >> lane) & 1ull) - 1u;
+					const uint32_t s1lo = (mlo >> 1) | (mhi << 31), s1hi = mhi >> 1;            // scalar
+					const uint32_t qs = pr + (mlo & 1u) - 1u;                                   // scalar
+					uint32_t q = qs + __builtin_amdgcn_mbcnt_hi(s1hi, __builtin_amdgcn_mbcnt_lo(s1lo, 0u));
 					q = min(q, nzc - 1u);                                    // lanes past the end of the last block
 					const uint2 se = s_cse[q];
 					obp = se.x + (t - s_cpref[q]) * R;
 					onv = ok ? min((uint32_t)R, se.y - obp) : 0u;
 					oav = s_caval[q];
 				};
-				uint32_t bp, nv; double av;
-				lookup(0, bp, nv, av);
 				const char *bbase = reinterpret_cast<const char *>(m.btup);
-				for (uint32_t step = 0; step < nsteps; ++step) {
-					const BPiece piece = *reinterpret_cast<const BPiece *>(bbase + (uint64_t)(ABL(ep, 64) ? (bp & 0xFFFFu) : bp) * 12u);
-					uint32_t nbp = bp, nnv = 0; double nav = 0.0;
-					if (step + 1 < nsteps) lookup(step + 1, nbp, nnv, nav);     // uniform branch
+				auto fetch = [&](uint32_t bp_) -> BPiece {
+					if (ABL(ep, 64)) bp_ &= 0xFFFFu;
+					// 12 * bp as a 32-bit offset from a scalar base where B is small enough (always, short of 3.5e8 tuples)
+					if (narrow) return *reinterpret_cast<const BPiece *>(bbase + (uint32_t)((bp_ << 3) + (bp_ << 2)));
+					return *reinterpret_cast<const BPiece *>(bbase + (uint64_t)bp_ * 12u);
+				};
+				auto accumulate = [&](const BPiece &piece, uint32_t nv_, double av_) {
 #pragma unroll
 					for (int u = 0; u < R; ++u) {
-						if ((uint32_t)u < nv) {
-							const uint32_t slot = ABL(ep, 64) ? (piece.w[3 * u] & (W - 1)) : piece.w[3 * u] - wbase;
-							if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[slot] = av; }         // no LDS accumulate
-							else if (MODE == MODE_COUNT) acc[slot] = 1.0;    // structural: touched
-							else atomicAdd(&acc[slot], av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
-						}
+						// a tuple past the segment's end goes to the lane's dump slot: straight-line code, no exec juggling
+						const uint32_t slot = (uint32_t)u < nv_ ? (ABL(ep, 64) ? (piece.w[3 * u] & (W - 1)) : piece.w[3 * u] - wbase) : (uint32_t)W + lane;
+						if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[slot] = av_; }          // no LDS accumulate
+						else if (MODE == MODE_COUNT) acc[slot] = 1.0;        // structural: touched
+						else atomicAdd(&acc[slot], av_ * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
 					}
+				};
+				STAMP(4);
+#if DENSE_DEPTH == 2
+				// two pieces in flight: the loads of step s+1 are issued before the products of step s are
+				// accumulated, the lookup of step s+2 runs under them
+				uint32_t bp0, nv0, bp1 = 0, nv1 = 0; double av0, av1 = 0.0;
+				lookup(0, bp0, nv0, av0);
+				BPiece p0 = fetch(bp0), p1 = p0;
+				if (nsteps > 1) lookup(1, bp1, nv1, av1);
+				for (uint32_t step = 0; step < nsteps; ++step) {
+					STAMP_COUNT(10);
+					if (step + 1 < nsteps) p1 = fetch(bp1);                  // uniform
+					uint32_t bp2 = 0, nv2 = 0; double av2 = 0.0;
+					if (step + 2 < nsteps) lookup(step + 2, bp2, nv2, av2);  // uniform
+					accumulate(p0, nv0, av0);
+					p0 = p1; nv0 = nv1; av0 = av1;
+					bp1 = bp2; nv1 = nv2; av1 = av2;
+				}
+#else
+				uint32_t bp, nv; double av;
+				lookup(0, bp, nv, av);
+				for (uint32_t step = 0; step < nsteps; ++step) {
+					STAMP_COUNT(10);
+					const BPiece piece = fetch(bp);
+					uint32_t nbp = bp, nnv = 0; double nav = 0.0;
+					if (step + 1 < nsteps) lookup(step + 1, nbp, nnv, nav);     // uniform branch
+					accumulate(piece, nv, av);
 					bp = nbp; nv = nnv; av = nav;
 				}
+#endif
 				Q0 = run;
+				STAMP(5);
 			}
 			lds_barrier();                                          // B3: segment tables and bitmap are free again
+			STAMP(6);
 			for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
 			lo = lo2; len = hi2 - lo2; a = a2;
 		}
@@ -1756,37 +1821,45 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			nlo = l2; nlen = nact ? h2 - l2 : 0u;
 		}
 		if (ABL(ep, 16)) continue;
+		STAMP(0);
 		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns.  (The last barrier of the
 		// chunk loop, B3, has every accumulate of this cell behind it; a cell with no product at all skips it and
 		// scans zeros, which is still ordered by the next cell's B1.)
+		// Kept lean, it runs once per cell over all W slots: with C = 1 and no scale vectors the emitted value IS the
+		// sum (sum * 1 * 1 * 1, multiply_sparse.hpp:242, is the same bits), and the index hash of column J0 + lane is
+		// mix64's product evaluated as X0 + lane * K with the group's X0 kept in scalar registers.
 		double v[GPW];
 		uint64_t nzmask[GPW];
 		uint32_t wcount = 0;
+		constexpr unsigned long long MIXK = 0x9E3779B97F4A7C15ull;
+		unsigned long long X0 = ((((unsigned long long)(uint32_t)rowid) << 32) | (unsigned long long)(wbase + wv * GPW * 64u)) * MIXK;   // uniform
+		double r_sum = 0;
 #pragma unroll
 		for (int gi = 0; gi < GPW; ++gi) {
 			int grp = wv * GPW + gi;
 			double x = acc[grp * 64 + lane];
 			acc[grp * 64 + lane] = 0.0;
-			int32_t col = (int32_t)(wbase + grp * 64 + lane);
 			bool ok;
-			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, col);
-			else ok = emit_value(ep, a_scale, col, x, &x);
+			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, (int32_t)(wbase + grp * 64 + lane));
+			else if (plain) ok = x != 0;
+			else ok = emit_value(ep, a_scale, (int32_t)(wbase + grp * 64 + lane), x, &x);
 			v[gi] = x;
 			nzmask[gi] = __ballot(ok);
 			wcount += (uint32_t)__popcll(nzmask[gi]);
+			if (MODE == MODE_DIGEST) {
+				unsigned long long h = X0 + laneK;
+				h ^= h >> 29;
+				d_hash += ok ? h : 0ull;
+				r_sum += ok ? x : 0.0;
+				X0 += 64ull * MIXK;
+			}
 		}
 		if (MODE == MODE_DIGEST) {
-			unsigned long long r_cnt = 0; double r_sum = 0;
-			for (int gi = 0; gi < GPW; ++gi) {
-				if ((nzmask[gi] >> lane) & 1ull) {
-					int32_t col = (int32_t)(wbase + (wv * GPW + gi) * 64 + lane);
-					++r_cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); r_sum += v[gi];
-				}
-			}
-			d_cnt += r_cnt; d_sum += r_sum;
+			if (lane == 0) d_cnt += wcount;
+			d_sum += r_sum;
 			if (sk.row_nnz) {
-				unsigned long long rc = wave_reduce_sum(r_cnt); double rs = wave_reduce_sum(r_sum);
-				if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+				double rs = wave_reduce_sum(r_sum);
+				if (lane == 0 && wcount) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], (unsigned long long)wcount); atomicAdd(&sk.row_sum[rowid], rs); }
 			}
 		} else {
 			if (lane == 0) s_wcnt[wv] = wcount;
@@ -1813,7 +1886,11 @@ __global__ __launch_bounds__(NT) void k_dense(const Cell *cells, uint32_t ncell,
 			}
 			__syncthreads();                                        // s_wcnt is reused by the next cell
 		}
+		STAMP(7);
 	}
+#ifdef SPSAMD_STAMPS
+	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
+#endif
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
 }
 
@@ -1916,6 +1993,7 @@ struct Heavy {
 	uint32_t *wptr = nullptr;        // window-major copy of B (dense cells): row pointer per window ...
 	BTup *btw = nullptr;             // ... and tuples
 	uint64_t nrowb = 0;
+	uint32_t nnzb = 0;
 };
 
 template <int MODE>
@@ -1946,14 +2024,33 @@ static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0
 	const uint32_t *widx = hv.bwin;
 	uint64_t kstride = hv.nwin1, wstride = 1;
 	if (hv.wptr) { widx = hv.wptr; kstride = 1; wstride = hv.nrowb; m.btup = hv.btw; }
+	const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;    // 32-bit byte offsets into B suffice
 	if (hv.W == 8192) {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, ep, sk);
+#ifdef SPSAMD_STAMPS
+		SinkParams sk2 = sk;
+		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
+		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk2);
+		{
+			std::vector<unsigned long long> h((size_t)grid * 12);
+			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipStreamSynchronize(c->stream));
+			double sum[12] = {}; double mx = 0;
+			for (unsigned g = 0; g < grid; ++g) { double t = 0; for (int i = 0; i < 12; ++i) { sum[i] += (double)h[(size_t)g * 12 + i]; if (i < 8) t += (double)h[(size_t)g * 12 + i]; } mx = std::max(mx, t); }
+			static const char *nm[12] = {"pre-B1", "B1wait", "compact", "B2wait", "tables", "steps", "B3wait", "scanout", "cells", "chunks", "steps#", "-"};
+			fprintf(stderr, "k_dense stamps (mean cycles per workgroup; max total %.3g):", mx);
+			for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.4g", nm[i], sum[i] / grid);
+			fprintf(stderr, "\n");
+		}
+		return;
+#endif
+		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
 	} else {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, ep, sk);
+		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
 	}
 	SPS_LAUNCH_CHECK();
 }
@@ -1993,6 +2090,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	hv.nwin1 = hv.nwin + 1;
 	const uint64_t nrowb = B.nrow + extra;
 	hv.nrowb = nrowb;
+	hv.nnzb = B.nnz;
 	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
 	k_bwin_prefill<<<dim3(4096), dim3(256), 0, st>>>(bptr, nrowb, hv.nwin1, hv.bwin);
 	SPS_LAUNCH_CHECK();
