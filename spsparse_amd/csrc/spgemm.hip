@@ -68,8 +68,11 @@ struct EmitParams {
 // Ablation switches exist in profiling builds only (-DSPSAMD_ABLATIONS); the shipped library has none.
 #ifdef SPSAMD_ABLATIONS
 #define ABL(ep, bit) ((ep).dbg & (bit))
+__device__ int g_abl;                       // the same switches for device functions that do not see EmitParams
+#define ABLG(bit) (g_abl & (bit))
 #else
 #define ABL(ep, bit) false
+#define ABLG(bit) false
 #endif
 
 struct DigestSlot { unsigned long long count; unsigned long long hash; double sum; unsigned long long pad; };
@@ -714,10 +717,13 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 			p = ok[u] ? p : p1 - 1;
 			uint32_t q = expand_lookup(X, p, pb);
 			uint32_t bp = X.cstart[q] + (p - X.cpref[q]);
-			const BTup t = m.btup[bp];
+			BTup t;
+			if (ABLG(0x2000)) { t.col = (int32_t)((p * 2654435761u) >> 12); t.vlo = 0; t.vhi = 0x3FF00000u; }     // no B read
+			else t = m.btup[bp];
 			col[u] = t.col;
 			pv[u] = (MODE != MODE_COUNT) ? X.caval[q] * btup_val(t) : 0.0;
 		}
+		if (ABLG(0x1000)) { bool any = false; for (int u = 0; u < U; ++u) any |= (pv[u] == 1.2345e-300); if (any) h_val[0] = 1.0; continue; }   // no insertion
 		uint32_t slot_of[U]; uint64_t newmask[U]; uint32_t nnew = 0;
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
@@ -739,7 +745,7 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 			nnew += (uint32_t)__popcll(newmask[u]);
 		}
 		// append the newly occupied slots of the whole step: one LDS atomic per wave and step
-		if (nnew) {                                                         // uniform
+		if (nnew && !ABLG(0x4000)) {                                        // uniform
 			uint32_t base = 0;
 			if (lane_id() == 0) base = lds_add_rtn_u32(s_nocc, nnew);
 			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1136,10 +1142,13 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 // tiles of up to NT / Lp cells (Lp = L rounded up to a power of two) and <= TILE_PB products.
 // Thread t of the workgroup owns (cell t / Lp, tuple t % Lp): ONE expansion serves every cell of
 // the tile; the cells are then accumulated one after the other in the same LDS table.
-constexpr int TILE_NT = 512;
-constexpr int TILE_T = 4096;
-constexpr int TILE_PB = 16384;          // products per tile, DIGEST / COUNT launches
-constexpr int TILE_PB_STORE = 12288;    // ... when the tiles also serve a STORE launch: its LDS then allows two workgroups per CU
+#ifndef TILE_NT_V
+#define TILE_NT_V 512
+#endif
+constexpr int TILE_NT = TILE_NT_V;
+constexpr int TILE_T = TILE_NT * 8;     // table slots: U = 4 products per thread fill it to one half
+constexpr int TILE_PB = TILE_NT * 32;   // products per tile, DIGEST / COUNT launches
+constexpr int TILE_PB_STORE = TILE_NT * 24;    // ... when the tiles also serve a STORE launch: its LDS then allows two workgroups per CU
 constexpr uint32_t TILE_LMAX = 256;
 constexpr uint32_t TILE_MAXCELLS = 16;
 
@@ -1168,6 +1177,9 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
 	DigestAcc dacc{0, 0, 0.0};
 	uint32_t flip = 0;
+#ifdef SPSAMD_STAMPS
+	unsigned long long st_[12] = {}; unsigned long long st_t = clock64();
+#endif
 
 	const uint32_t stride = gridDim.x;
 	const uint32_t tlast = ntile - 1;
@@ -1209,15 +1221,20 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
 
+		STAMP_COUNT(8);
+		STAMP(0);
 		lds_barrier();                                              // previous tile fully emitted
+		STAMP(1);
 		uint32_t total, nzc, ex;
 		expand_load(X, lo, len, a, &total, &nzc, flip, &ex);
 		if (myei == 0 && myc < tile.ncells) cellP[myc] = ex;       // first product of each cell
 		if (tid == 0) { cellP[tile.ncells] = total; s_nocc = 0; }
 		// segment ids of the cells of this tile: thread (c, 0) holds cell c's
 		const uint32_t seg_of_mine = myseg;
+		STAMP(2);
 		if (total) expand_batch(X, 0, total, nzc);
 		else lds_barrier();
+		STAMP(3);
 		// stage C: B segment bounds of the next tile
 		{
 			const uint32_t *bw = bwin + (uint64_t)nk * nwin1;
@@ -1225,13 +1242,17 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 			nlo = nlo_; nlen = nact ? nhi_ - nlo_ : 0u; nseg_ = ntc.seg;
 		}
 		for (uint32_t c = 0; c < tile.ncells; ++c) {
+			STAMP_COUNT(9);
+			STAMP(0);
 			const uint32_t p0 = cellP[c], p1 = cellP[c + 1];
 			if (ep.ordered) {
 				// the cell's products [p0, p1) are whole segments (a segment belongs to one cell)
 				const uint32_t q0 = expand_lookup(X, p0, 0), q1 = expand_lookup(X, p1 - 1, 0) + 1;
 				hash_products_ordered<T, NT, PB, MODE>(X, q0, q1, m, h_key, h_val, occ, &s_nocc);
 			} else hash_products<T, NT, PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
+			STAMP(4);
 			lds_barrier();
+			STAMP(5);
 			const uint32_t nocc = s_nocc;
 			// the cell's output segment id lives in thread (c, 0): broadcast through LDS
 			if (myc == c && myei == 0) scr32[NT / 64] = seg_of_mine;
@@ -1244,10 +1265,15 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 				colbase = (uint32_t)tcc.wa << ep.wshift;
 				colbits = ep.wshift + (tcc.wb - tcc.wa > 1 ? 32 - __builtin_clz((uint32_t)(tcc.wb - tcc.wa) - 1u) : 0);
 			}
+			STAMP(6);
 			hash_emit<T, NT, MODE>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
+			STAMP(7);
 			lds_barrier();
 		}
 	}
+#ifdef SPSAMD_STAMPS
+	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
+#endif
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
 }
 
@@ -1416,6 +1442,7 @@ constexpr int CLS_DENSE = NCLS - 1;
 constexpr uint32_t CELL_CAP = 4096;      // largest hash cell (T = 8192)
 constexpr uint32_t CELL_CAP_DEFAULT = 2048;      // greedy grouping target of the hash cells (measured best on R-MAT scale-20)
 constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // a single window above this becomes a dense cell
+constexpr uint32_t DIRECT_MIN_DEFAULT = 256;     // a single window of a tile row above this becomes a direct cell
 __device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 1536 ? 1 : (prods <= 2048 ? 2 : 3)); }
 
 struct CellBases { uint32_t *base[NCLS]; };      // per heavy row: first cell index in each class list
@@ -1423,13 +1450,16 @@ struct CellLists { Cell *list[NCLS]; };
 
 // Greedy grouping of a heavy row's windows into cells.  WRITE = false counts
 // the cells per class (and the row's segment count); WRITE = true emits them.
-struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; };
+struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; int by_items; };
+// Two kinds of tile: [0] hash cells (ranges of sparse windows, LDS hash table), [1] direct cells (ONE window holding
+// more than direct_min products, dense window accumulator with claim-by-exchange emission: k_direct_tiles)
+struct TileKinds { TileBases k[2]; uint32_t direct_min; };
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
 	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap, uint32_t dense_min,
 	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod,
-	TileBases tb)
+	TileKinds tk)
 {
 	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
 	if (h >= nheavy) return;
@@ -1441,35 +1471,43 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	unsigned long long np[NCLS] = {};
 	uint32_t ordinal = 0;
 	uint32_t cur = 0, start = 0, last = 0;
-	// rows with few A tuples: their hash cells are grouped into tiles that share one expansion
+	// rows with few A tuples: their hash / direct cells are grouped into tiles that share one expansion
 	const uint32_t L = proto.end - proto.beg;
-	const bool tileable = tb.enabled && L <= TILE_LMAX;
+	const bool tileable = tk.k[0].enabled && L <= TILE_LMAX;
+	const bool direct_ok = tileable && tk.k[1].enabled;
 	uint32_t lsh = 0;
 	while ((1u << lsh) < L) ++lsh;
 	const uint32_t G = min((uint32_t)TILE_NT >> lsh, TILE_MAXCELLS);
-	uint32_t ntc = 0, ntl = 0;                    // tile cells / tiles emitted so far for this row
-	uint32_t tcnt = 0, tprods = 0, tfirst = 0, twa0 = 0;   // the open tile
-	auto close_tile = [&]() {
-		if (!tcnt) return;
+	uint32_t ntc[2] = {0, 0}, ntl[2] = {0, 0};                        // tile cells / tiles emitted so far for this row
+	uint32_t tcnt[2] = {0, 0}, tcost[2] = {0, 0}, tprods[2] = {0, 0}, tfirst[2] = {0, 0}, twa0[2] = {0, 0};   // the open tiles
+	auto close_tile = [&](int kd) {
+		if (!tcnt[kd]) return;
 		if (WRITE) {
-			Tile t; t.beg = proto.beg; t.end = proto.end; t.rowid = proto.rowid; t.first = tb.tcbase[h] + tfirst; t.ncells = tcnt;
-			t.wa0 = twa0; t.prods = tprods; t.pad = 0;
-			tb.tiles[tb.tlbase[h] + ntl] = t;
+			Tile t; t.beg = proto.beg; t.end = proto.end; t.rowid = proto.rowid; t.first = tk.k[kd].tcbase[h] + tfirst[kd]; t.ncells = tcnt[kd];
+			t.wa0 = twa0[kd]; t.prods = tprods[kd]; t.pad = 0;
+			tk.k[kd].tiles[tk.k[kd].tlbase[h] + ntl[kd]] = t;
 		}
-		++ntl; tcnt = 0; tprods = 0;
+		++ntl[kd]; tcnt[kd] = 0; tcost[kd] = 0; tprods[kd] = 0;
+	};
+	// cost of a cell against the tile's capacity: products for a hash tile; for a direct tile an upper bound of its
+	// ITEMS (R tuples each, at most one partial item per A tuple) rounded up to whole 64-item blocks
+	auto tile_cell = [&](int kd, uint32_t wa, uint32_t wb, uint32_t prods) {
+		const uint32_t cost = tk.k[kd].by_items ? ((prods / DENSE_R + L + 63u) & ~63u) + 64u : prods;
+		if (tcnt[kd] == G || tcost[kd] + cost > tk.k[kd].pb) close_tile(kd);
+		if (!tcnt[kd]) { tfirst[kd] = ntc[kd]; twa0[kd] = wa; }
+		if (WRITE) {
+			TCell tc; tc.wa = (uint16_t)wa; tc.wb = (uint16_t)wb; tc.seg = segbase ? segbase[r] + ordinal : 0; tc.prods = prods;
+			tk.k[kd].tcells[tk.k[kd].tcbase[h] + ntc[kd]] = tc;
+		}
+		++ntc[kd]; ++tcnt[kd]; tcost[kd] += cost; tprods[kd] += prods;
+		np[0] += prods;                                                  // counted with the hash products
+		++ordinal;
 	};
 	auto flush = [&]() {
 		if (!cur) return;
 		if (tileable && cur <= (uint32_t)(TILE_T / 2)) {
-			if (tcnt == G || tprods + cur > tb.pb) close_tile();
-			if (!tcnt) { tfirst = ntc; twa0 = start; }
-			if (WRITE) {
-				TCell tc; tc.wa = (uint16_t)start; tc.wb = (uint16_t)(last + 1); tc.seg = segbase ? segbase[r] + ordinal : 0; tc.prods = cur;
-				tb.tcells[tb.tcbase[h] + ntc] = tc;
-			}
-			++ntc; ++tcnt; tprods += cur;
-			np[0] += cur;                           // counted with the hash products
-			++ordinal; cur = 0;
+			tile_cell(0, start, last + 1, cur);
+			cur = 0;
 			return;
 		}
 		int cls = hash_class(cur);
@@ -1496,6 +1534,10 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 				lists.list[CLS_DENSE][base.base[CLS_DENSE][h] + n[CLS_DENSE]] = d;
 			}
 			++n[CLS_DENSE]; np[CLS_DENSE] += c; ++ordinal;
+		} else if (direct_ok && c > tk.direct_min) {
+			// one window of a tile row with enough products to pay for a cell of its own: direct cell
+			flush();
+			tile_cell(1, w, w + 1, c);
 		} else if (c > cell_cap) {
 			// too large for a group, too small for a dense window: a hash cell of its own
 			flush();
@@ -1508,12 +1550,13 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		}
 	}
 	flush();
-	close_tile();
+	close_tile(0);
+	close_tile(1);
 	if (!WRITE) {
 #pragma unroll
 		for (int k = 0; k < NCLS; ++k) { cnt.base[k][h] = n[k]; if (np[k]) atomicAdd(&clsprod[k], np[k]); }
 		nseg[r] = ordinal;
-		if (tb.enabled) { tb.ntc[h] = ntc; tb.ntl[h] = ntl; }
+		for (int kd = 0; kd < 2; ++kd) if (tk.k[kd].enabled) { tk.k[kd].ntc[h] = ntc[kd]; tk.k[kd].ntl[h] = ntl[kd]; }
 	}
 }
 
@@ -1894,6 +1937,541 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
 }
 
+// ====================================================================== tiles, second generation
+//
+// A tile is up to 16 cells of ONE heavy row with few A tuples (L <= 256) that share one expansion
+// of the row's A tuples: thread t owns (cell t / Lp, tuple t % Lp), Lp = L rounded up to a power
+// of two.  The expansion works in ITEMS of R consecutive B tuples like k_dense: a non-empty
+// segment is ceil(len / R) items, the items of the tile are numbered cell by cell with every
+// cell's first item at a multiple of 64, every segment sets the bit of its first item, and each
+// wave keeps the bitmap and its popcount prefix in registers: an item's segment is found with
+// v_readlane + mbcnt and ONE LDS round trip.
+template <int NT, int NWORD>
+struct TileX {
+	uint16_t cpref[NT + 2];          // compacted segments: first item (a tile has at most 64 NWORD <= 16384 items)
+	uint2 cse[NT];                   // first tuple of the segment, one past its last
+	double caval[NT];                // the A value
+	unsigned long long bmask[NWORD]; // first-item bits
+	uint32_t scrL[2][NT / 64], scrN[2][NT / 64];
+	uint32_t cellI[TILE_MAXCELLS + 1];       // first item of every cell (+ end), multiples of 64
+	uint32_t cellseg[TILE_MAXCELLS];         // output segment id of every cell
+	uint32_t cellw[TILE_MAXCELLS];           // wa | wb << 16 of every cell
+};
+
+// Contains two barriers (B1 after the per-wave totals, B2 after the tables are written); the first one also
+// separates the previous tile's last LDS traffic from this tile's.
+template <int NT, int NWORD>
+__device__ __forceinline__ void tile_expand(TileX<NT, NWORD> &X, uint32_t lsh, uint32_t ncells, uint32_t lo, uint32_t len, double a,
+	uint32_t myseg, uint32_t myw, uint32_t &flip, uint32_t *total_out, uint32_t *nzc_out)
+{
+	constexpr int NW = NT / 64;
+	constexpr int R = DENSE_R;
+	const unsigned tid = threadIdx.x, lane = lane_id();
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
+	const uint32_t myc = tid >> lsh, myei = tid & ((1u << lsh) - 1u);
+	const uint32_t items = (len + R - 1) / R;
+	uint32_t incl;                                                  // inclusive item prefix inside the wave, cell starts aligned
+	{
+		// cells are runs of Lp = 2^lsh consecutive threads: whole waves (Lp >= 64) or 64 / Lp cells per wave
+		const uint32_t x = wave_inclusive_scan_u32(items);
+		if (lsh < 6) {
+			// several cells in this wave: the start of each is rounded up to 64 items, serially over the cells of
+			// the wave with wave-uniform lane reads (cells are numbered from thread 0 and a tile has at most 16)
+			const uint32_t cells_here = min(64u >> lsh, TILE_MAXCELLS);
+			uint32_t carry = 0, out = 0;                                // carry: aligned total before the current cell
+			for (uint32_t cc = 0; cc < cells_here; ++cc) {
+				const uint32_t first_lane = cc << lsh, last_lane = first_lane + (1u << lsh) - 1u;
+				const uint32_t before = first_lane ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(first_lane - 1u)) : 0u;
+				const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)last_lane);
+				if ((lane >> lsh) == cc) out = carry + (x - before);
+				carry = (carry + (upto - before) + 63u) & ~63u;
+			}
+			incl = out;
+			if (lane == 63) X.scrL[flip][wv] = carry;                   // aligned items of the whole wave
+		} else {
+			incl = x;
+			if (lane == 63) X.scrL[flip][wv] = x;                       // a cell spans 2^(lsh-6) whole waves: aligned below
+		}
+	}
+	const uint64_t nzm = __ballot(len != 0);
+	const uint32_t wrank = (uint32_t)__popcll(nzm & lanemask_lt());
+	if (lane == 0) X.scrN[flip][wv] = (uint32_t)__popcll(nzm);
+	lds_barrier();                                                  // B1
+	uint32_t baseL = 0, baseN = 0, total = 0, nzc = 0;
+	{
+		const uint32_t wpc = lsh > 6 ? (1u << (lsh - 6)) : 1u;          // waves per cell
+#pragma unroll
+		for (int q = 0; q < NW; ++q) {
+			const uint32_t l = X.scrL[flip][q], n = X.scrN[flip][q];
+			if ((q & (wpc - 1u)) == 0) total = (total + 63u) & ~63u;        // a cell begins with this wave
+			if (q == (int)wv) baseL = total;
+			if (q < (int)wv) baseN += n;
+			total += l; nzc += n;
+		}
+		total = (total + 63u) & ~63u;
+	}
+	flip ^= 1u;
+	const uint32_t myfirst = baseL + incl - items;
+	if (len) {
+		const uint32_t rank = baseN + wrank;
+		X.cpref[rank] = (uint16_t)myfirst;
+		X.cse[rank] = make_uint2(lo, lo + len);
+		X.caval[rank] = a;
+		atomicOr(&X.bmask[myfirst >> 6], 1ull << (myfirst & 63u));
+	}
+	if (myei == 0 && myc < ncells) { X.cellI[myc] = myfirst; X.cellseg[myc] = myseg; X.cellw[myc] = myw; }    // a cell's first thread: its items start here
+	if (tid == 0) X.cellI[ncells] = total;
+	lds_barrier();                                                  // B2
+	*total_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
+	*nzc_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)nzc);
+}
+
+// The per-wave register copy of the item bitmap and its popcount prefix: word x * 64 + l in lane l.
+template <int WPL>
+struct TileTab { unsigned long long mw[WPL]; uint32_t pre[WPL]; };
+
+template <int NT, int NWORD>
+__device__ __forceinline__ void tile_tables(const TileX<NT, NWORD> &X, TileTab<NWORD / 64> &tab)
+{
+	uint32_t run = 0;
+#pragma unroll
+	for (int x = 0; x < NWORD / 64; ++x) {
+		tab.mw[x] = X.bmask[x * 64 + lane_id()];
+		const uint32_t cnt = (uint32_t)__popcll(tab.mw[x]);
+		const uint32_t inc2 = wave_inclusive_scan_u32(cnt);
+		tab.pre[x] = run + inc2 - cnt;
+		run += (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
+	}
+}
+
+// Item (b << 6) + lane of block b (wave-uniform) -> first tuple, number of valid tuples, A value.  i1 = end of the
+// cell's item range.  An aligned cell start leaves positions at the END of the previous cell's last block that hold no
+// item: they resolve to that cell's last segment with an offset past its end -- no valid tuple.
+template <int NT, int NWORD>
+__device__ __forceinline__ void tile_lookup(const TileX<NT, NWORD> &X, const TileTab<NWORD / 64> &tab, uint32_t nzc, uint32_t b, uint32_t i1,
+	uint32_t &obp, uint32_t &onv, double &oav)
+{
+	constexpr int R = DENSE_R;
+	const uint32_t t = (b << 6) + lane_id();
+	uint32_t mlo = 0, mhi = 0, pr = 0;
+#pragma unroll
+	for (int x = 0; x < NWORD / 64; ++x) {
+		if ((b >> 6) == (uint32_t)x) {                                  // uniform
+			mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tab.mw[x], (int)(b & 63u));
+			mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tab.mw[x] >> 32), (int)(b & 63u));
+			pr = (uint32_t)__builtin_amdgcn_readlane((int)tab.pre[x], (int)(b & 63u));
+		}
+	}
+	const uint32_t s1lo = (mlo >> 1) | (mhi << 31), s1hi = mhi >> 1;
+	const uint32_t qs = pr + (mlo & 1u) - 1u;
+	uint32_t q = qs + __builtin_amdgcn_mbcnt_hi(s1hi, __builtin_amdgcn_mbcnt_lo(s1lo, 0u));
+	q = min(q, nzc - 1u);
+	const uint2 se = X.cse[q];
+	obp = se.x + (t - (uint32_t)X.cpref[q]) * R;
+	onv = (t < i1 && obp < se.y) ? min((uint32_t)R, se.y - obp) : 0u;
+	oav = X.caval[q];
+}
+
+__device__ __forceinline__ BPiece fetch_piece(const char *bbase, uint32_t bp, uint32_t narrow)
+{
+	// 12 * bp as a 32-bit offset from a scalar base where B is small enough (always, short of 3.5e8 tuples)
+	if (narrow) return *reinterpret_cast<const BPiece *>(bbase + (uint32_t)((bp << 3) + (bp << 2)));
+	return *reinterpret_cast<const BPiece *>(bbase + (uint64_t)bp * 12u);
+}
+
+// ---- hash tiles: cells are ranges [wa, wb) of sparse column windows, accumulated in the LDS hash table ----
+// Insertion: the R first probes of a lane are in flight together (ds_cmpswap with return), the rare collisions are
+// then walked one by one; the values follow with ds_add_f64; the newly occupied slots of a step are appended to the
+// occupied list with one LDS fetch-add per wave.  The first block of the NEXT cell is looked up and its B tuples
+// requested before the current cell is emitted, so that latency is hidden behind the emission.
+constexpr int TILE2_NT = 512;
+constexpr int TILE2_T = 4096;
+constexpr int TILE2_ITEMS = 8192;        // items per tile: bitmap of 128 words, two per lane
+
+template <int MODE>
+__global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
+	const uint32_t *bwin, uint32_t nwin1, uint32_t narrow, EmitParams ep, SinkParams sk)
+{
+	constexpr int NT = TILE2_NT, T = TILE2_T, NW = NT / 64, R = DENSE_R;
+	constexpr int NWORD = TILE2_ITEMS / 64;
+	constexpr int MAXST = 3;                 // 64-item blocks of one cell per wave (T / 2 products: at most T/2/R + L items, plus alignment)
+	__shared__ int32_t h_key[T + 64];        // + one dump slot per lane: the first probes are issued unconditionally
+	__shared__ double h_val[MODE == MODE_COUNT ? 1 : T];
+	__shared__ uint16_t occ[T / 2];
+	__shared__ uint64_t s_sort[MODE == MODE_STORE ? T / 2 : 1];
+	__shared__ uint16_t s_cnt[MODE == MODE_STORE ? 16 * ((T / 2 + NT - 1) / NT) * (NT / 64) : 1];
+	__shared__ TileX<NT, NWORD> X;
+	__shared__ uint32_t scr32[NW + 1];
+	__shared__ uint32_t s_nocc;
+	__shared__ unsigned long long s_u64[2 * NW];
+	__shared__ double s_f64[NW];
+
+	const unsigned tid = threadIdx.x, lane = lane_id();
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
+	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
+	if (tid < 64) h_key[T + tid] = -1;
+	for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;
+	if (tid == 0) s_nocc = 0;
+	DigestAcc dacc{0, 0, 0.0};
+	uint32_t flip = 0;
+	const char *bbase = reinterpret_cast<const char *>(m.btup);
+#ifdef SPSAMD_STAMPS
+	unsigned long long st_[12] = {}; unsigned long long st_t = clock64();
+#endif
+
+	const uint32_t stride = gridDim.x;
+	const uint32_t tlast = ntile - 1;
+	// three-stage branch-free prefetch: tile record -> (A tuple, cell window range) -> B segment bounds
+	Tile rec1 = tiles[min(blockIdx.x, tlast)];
+	Tile rec2 = tiles[min(blockIdx.x + stride, tlast)];
+	uint32_t nlo, nlen, nseg_, nw_; double na;
+	{
+		const uint32_t L = rec1.end - rec1.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		const uint32_t c = tid >> lsh, ei = tid & ((1u << lsh) - 1u);
+		const bool act = c < rec1.ncells && ei < L;
+		const uint32_t ec = rec1.beg + (ei < L ? ei : 0u);
+		const TCell tc = tcells[rec1.first + (c < rec1.ncells ? c : 0u)];
+		const uint32_t *bw = bwin + (uint64_t)(uint32_t)m.acol[ec] * nwin1;
+		const uint32_t lo = bw[tc.wa], hi = bw[tc.wb];
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u; nseg_ = tc.seg; nw_ = (uint32_t)tc.wa | ((uint32_t)tc.wb << 16);
+	}
+	__syncthreads();
+	for (uint32_t ti = blockIdx.x; ti < ntile; ti += stride) {
+		const Tile tile = rec1;
+		const uint32_t lo = nlo, len = nlen, myseg = nseg_, myw = nw_; const double a = na;
+		const uint32_t L = tile.end - tile.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		lsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsh);
+		const int32_t rowid = tile.rowid;
+		// stage A / B for the next tile
+		rec1 = rec2;
+		rec2 = tiles[min(ti + 2 * stride, tlast)];
+		const bool has_next = ti + stride < ntile;
+		const uint32_t nL = rec1.end - rec1.beg;
+		uint32_t nsh = 0;
+		while ((1u << nsh) < nL) ++nsh;
+		const uint32_t nc = tid >> nsh, nei = tid & ((1u << nsh) - 1u);
+		const bool nact = has_next && nc < rec1.ncells && nei < nL;
+		const uint32_t nec = rec1.beg + (nei < nL ? nei : 0u);
+		const TCell ntc = tcells[rec1.first + (nc < rec1.ncells ? nc : 0u)];
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
+
+		uint32_t total, nzc;
+		STAMP_COUNT(8);
+		STAMP(0);
+		tile_expand(X, lsh, tile.ncells, lo, len, a, myseg, myw, flip, &total, &nzc);
+		STAMP(1);
+		// stage C: B segment bounds of the next tile
+		{
+			const uint32_t *bw = bwin + (uint64_t)(uint32_t)nk * nwin1;
+			const uint32_t nlo_ = bw[ntc.wa], nhi_ = bw[ntc.wb];
+			nlo = nlo_; nlen = nact ? nhi_ - nlo_ : 0u; nseg_ = ntc.seg; nw_ = (uint32_t)ntc.wa | ((uint32_t)ntc.wb << 16);
+		}
+		if (total == 0 || nzc == 0) {                               // uniform; cannot happen for real tiles
+			if (MODE != MODE_DIGEST) for (uint32_t c = tid; c < tile.ncells; c += NT) { if (MODE == MODE_COUNT) sk.segcount[X.cellseg[c]] = 0; else sk.segactual[X.cellseg[c]] = 0; }
+			continue;
+		}
+		TileTab<NWORD / 64> tab;
+		tile_tables(X, tab);
+
+		// first block of cell 0, prefetched like every later cell's
+		uint32_t pbp, pnv; double pav;
+		tile_lookup(X, tab, nzc, (X.cellI[0] >> 6) + wv, X.cellI[1], pbp, pnv, pav);
+		BPiece ppiece = fetch_piece(bbase, pbp, narrow);
+		STAMP(2);
+		for (uint32_t c = 0; c < tile.ncells; ++c) {
+			STAMP_COUNT(9);
+			const uint32_t i0 = X.cellI[c], i1 = X.cellI[c + 1];
+			const uint32_t seg = X.cellseg[c];
+			const uint32_t nblk = (i1 - i0) >> 6;
+			if (nblk > (uint32_t)(MAXST * NW) && tid == 0) atomicOr(sk.err, 2u);     // never: k_cells bounds a cell's items
+#pragma unroll
+			for (int st = 0; st < MAXST; ++st) {
+				const uint32_t bl = (uint32_t)st * NW + wv;
+				if (st > 0 && bl >= nblk) break;                            // wave-uniform (step 0 always runs: its piece is prefetched)
+				uint32_t nv; double av; BPiece piece;
+				if (st == 0) { nv = bl < nblk ? pnv : 0u; av = pav; piece = ppiece; }
+				else {
+					uint32_t bp;
+					tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
+					piece = fetch_piece(bbase, bp, narrow);
+				}
+				// ---- R first probes in flight, then the collisions
+				uint32_t h[R]; int32_t old[R]; bool isnew[R];
+#pragma unroll
+				for (int u = 0; u < R; ++u) {
+					// (a tuple past the segment's end probes the lane's dump slot: no branch, so the R atomics overlap)
+					h[u] = (uint32_t)u < nv ? hash_slot<T>((int32_t)piece.w[3 * u]) : (uint32_t)T + lane;
+					old[u] = atomicCAS(&h_key[h[u]], -1, (int32_t)piece.w[3 * u]);
+				}
+				uint64_t newmask[R]; uint32_t nnew = 0;
+#pragma unroll
+				for (int u = 0; u < R; ++u) {
+					const int32_t col = (int32_t)piece.w[3 * u];
+					isnew[u] = false;
+					if ((uint32_t)u < nv) {
+						int32_t o = old[u];
+						while (o != -1 && o != col) {
+							h[u] = (h[u] + 1) & (T - 1);
+							o = atomicCAS(&h_key[h[u]], -1, col);
+						}
+						isnew[u] = o == -1;
+						if (MODE != MODE_COUNT) atomicAdd(&h_val[h[u]], av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
+					}
+					newmask[u] = __ballot(isnew[u]);
+					nnew += (uint32_t)__popcll(newmask[u]);
+				}
+				if (nnew) {                                                 // uniform: one LDS fetch-add per wave and step
+					uint32_t base = 0;
+					if (lane == 0) base = lds_add_rtn_u32(&s_nocc, nnew);
+					base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						if (isnew[u]) occ[base + __popcll(newmask[u] & lanemask_lt())] = (uint16_t)h[u];
+						base += (uint32_t)__popcll(newmask[u]);
+					}
+				}
+			}
+			STAMP(3);
+			lds_barrier();                                          // the cell's products are in the table
+			STAMP(4);
+			const uint32_t nocc = s_nocc;
+			// the next cell's first block: lookup and B request issued now, consumed after the emission
+			if (c + 1 < tile.ncells) {                              // uniform
+				tile_lookup(X, tab, nzc, (i1 >> 6) + wv, X.cellI[c + 2], pbp, pnv, pav);
+				ppiece = fetch_piece(bbase, pbp, narrow);
+			}
+			uint32_t colbase = 0, colbits = 0;
+			if (MODE == MODE_STORE) {
+				const uint32_t wab = X.cellw[c];
+				const uint32_t wa = wab & 0xFFFFu, wb = wab >> 16;
+				colbase = wa << ep.wshift;
+				colbits = ep.wshift + (wb - wa > 1 ? 32 - __builtin_clz(wb - wa - 1u) : 0);
+			}
+			STAMP(5);
+			hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
+			if (tid == 0) s_nocc = 0;
+			STAMP(6);
+			lds_barrier();                                          // table clean, counter reset: next cell may insert
+			STAMP(7);
+		}
+		for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;     // (every wave is past its last lookup)
+	}
+#ifdef SPSAMD_STAMPS
+	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
+#endif
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
+}
+
+// ---- direct tiles: ONE window per cell, dense accumulator, claim-by-exchange emission ----------------------
+// A direct cell holds more than direct_min products in one window of a tile row -- too few to pay for k_dense's scan
+// of all W accumulator slots.  It
+//   accumulates  into the dense window accumulator, slot = column - window base, with ds_add_f64, and
+//   emits        by CLAIM: every product thread exchanges its slot with 0; the one thread that gets a non-zero
+//                sum back owns the output tuple.  No probing, no list of occupied slots, no scan of the window,
+//                and the accumulator is clean again -- two barriers per cell.
+// COO order: the claimed columns set bits in a window bitmap and a tuple's place is its rank (prefix popcount).
+// (Measured on R-MAT scale-20: pays only for cells above ~1000 products -- a cell is a latency chain of two
+// barriers whatever its size, and small cells leave most lanes idle -- hence the default threshold.)
+template <int W, int NT, int MODE>
+__global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
+	const uint32_t *wptr, uint64_t nrowb, uint32_t narrow, EmitParams ep, SinkParams sk)
+{
+	constexpr int NW = NT / 64;
+	constexpr uint32_t WSHIFT = W == 8192 ? 13 : 14;
+	constexpr int R = DENSE_R;
+	constexpr int NWORD = W / 64;            // item bitmap words of one tile (<= W items)
+	constexpr int MAXST = 3;                 // 64-item blocks of one cell per wave
+	__shared__ double acc[W + 64];
+	__shared__ TileX<NT, NWORD> X;
+	__shared__ unsigned long long s_cbm[MODE == MODE_STORE ? NWORD : 1];     // claimed columns of the current cell (COO order)
+	__shared__ uint32_t s_cpre[MODE == MODE_STORE ? NWORD + 1 : 1];
+	__shared__ uint32_t s_count;
+	__shared__ unsigned long long s_u64[2 * NW];
+	__shared__ double s_f64[NW];
+
+	const unsigned tid = threadIdx.x, lane = lane_id();
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
+	for (int q = tid; q < W + 64; q += NT) acc[q] = 0.0;
+	for (int q = tid; q < NWORD; q += NT) { X.bmask[q] = 0ull; if (MODE == MODE_STORE) s_cbm[q] = 0ull; }
+	if (tid == 0) s_count = 0;
+	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;
+	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;
+	uint32_t flip = 0;
+	const char *bbase = reinterpret_cast<const char *>(m.btup);
+
+	const uint32_t stride = gridDim.x;
+	const uint32_t tlast = ntile - 1;
+	Tile rec1 = tiles[min(blockIdx.x, tlast)];
+	Tile rec2 = tiles[min(blockIdx.x + stride, tlast)];
+	uint32_t nlo, nlen, nseg_, nw_; double na;
+	{
+		const uint32_t L = rec1.end - rec1.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		const uint32_t c = tid >> lsh, ei = tid & ((1u << lsh) - 1u);
+		const bool act = c < rec1.ncells && ei < L;
+		const uint32_t ec = rec1.beg + (ei < L ? ei : 0u);
+		const TCell tc = tcells[rec1.first + (c < rec1.ncells ? c : 0u)];
+		const uint32_t *bw = wptr + (uint64_t)tc.wa * nrowb + (uint32_t)m.acol[ec];
+		const uint32_t lo = bw[0], hi = bw[1];
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u; nseg_ = tc.seg; nw_ = tc.wa;
+	}
+	__syncthreads();
+	for (uint32_t ti = blockIdx.x; ti < ntile; ti += stride) {
+		const Tile tile = rec1;
+		const uint32_t lo = nlo, len = nlen, myseg = nseg_, myw = nw_; const double a = na;
+		const uint32_t L = tile.end - tile.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		lsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsh);
+		const int32_t rowid = tile.rowid;
+		const double a_scale = row_scale(ep, rowid);
+		rec1 = rec2;
+		rec2 = tiles[min(ti + 2 * stride, tlast)];
+		const bool has_next = ti + stride < ntile;
+		const uint32_t nL = rec1.end - rec1.beg;
+		uint32_t nsh = 0;
+		while ((1u << nsh) < nL) ++nsh;
+		const uint32_t nc = tid >> nsh, nei = tid & ((1u << nsh) - 1u);
+		const bool nact = has_next && nc < rec1.ncells && nei < nL;
+		const uint32_t nec = rec1.beg + (nei < nL ? nei : 0u);
+		const TCell ntc = tcells[rec1.first + (nc < rec1.ncells ? nc : 0u)];
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
+
+		uint32_t total, nzc;
+		tile_expand(X, lsh, tile.ncells, lo, len, a, myseg, myw, flip, &total, &nzc);
+		{
+			const uint32_t *bw = wptr + (uint64_t)ntc.wa * nrowb + (uint32_t)nk;
+			const uint32_t nlo_ = bw[0], nhi_ = bw[1];
+			nlo = nlo_; nlen = nact ? nhi_ - nlo_ : 0u; nseg_ = ntc.seg; nw_ = ntc.wa;
+		}
+		if (total == 0 || nzc == 0) {                               // uniform; cannot happen for real tiles
+			if (MODE != MODE_DIGEST) for (uint32_t c = tid; c < tile.ncells; c += NT) { if (MODE == MODE_COUNT) sk.segcount[X.cellseg[c]] = 0; else sk.segactual[X.cellseg[c]] = 0; }
+			continue;
+		}
+		TileTab<NWORD / 64> tab;
+		tile_tables(X, tab);
+
+		for (uint32_t c = 0; c < tile.ncells; ++c) {
+			const uint32_t i0 = X.cellI[c], i1 = X.cellI[c + 1];      // multiples of 64; i1 = next cell's (aligned) start
+			const uint32_t wbase = X.cellw[c] << WSHIFT;
+			const uint32_t seg = X.cellseg[c];
+			const uint32_t nblk = (i1 - i0) >> 6;
+			if (nblk > (uint32_t)(MAXST * NW) && tid == 0) atomicOr(sk.err, 2u);     // never: k_cells bounds a direct cell's items
+			// ---- accumulate: block b0 + st * NW + wv per wave and step; the slots are kept for the claim
+			uint32_t ks[MAXST][R];
+			double kv[MODE == MODE_STORE ? MAXST : 1][MODE == MODE_STORE ? R : 1];
+#pragma unroll
+			for (int st = 0; st < MAXST; ++st) {
+#pragma unroll
+				for (int u = 0; u < R; ++u) ks[st][u] = (uint32_t)W + lane;
+				const uint32_t bl = (uint32_t)st * NW + wv;
+				if (bl < nblk) {                                            // wave-uniform
+					uint32_t bp, nv; double av;
+					tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
+					const BPiece piece = fetch_piece(bbase, bp, narrow);
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						const uint32_t slot = (uint32_t)u < nv ? piece.w[3 * u] - wbase : (uint32_t)W + lane;
+						ks[st][u] = slot;
+						if (MODE == MODE_COUNT) acc[slot] = 1.0;
+						else atomicAdd(&acc[slot], av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
+					}
+				}
+			}
+			lds_barrier();                                          // every product of the cell is in the accumulator
+			// ---- claim: exchange the slot with 0; a non-zero answer makes this thread the tuple's owner
+			unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+			uint32_t mycount = 0; double mysum = 0.0;
+#pragma unroll
+			for (int st = 0; st < MAXST; ++st) {
+				if ((uint32_t)st * NW + wv < nblk) {                        // wave-uniform
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						const uint32_t slot = ks[st][u];
+						bool own = false;
+						double v = 0.0;
+						if (slot < (uint32_t)W) {
+							const unsigned long long old = atomicExch(&acc64[slot], 0ull);
+							v = __longlong_as_double((long long)old);
+							const int32_t col = (int32_t)(wbase + slot);
+							if (MODE == MODE_COUNT) own = (v != 0) && col_allowed(ep, col);
+							else if (plain) own = v != 0;
+							else own = emit_value(ep, a_scale, col, v, &v);
+						}
+						if constexpr (MODE == MODE_DIGEST) {
+							if (own) { ++mycount; d_hash += mix64((uint32_t)rowid, wbase + slot); mysum += v; }
+						} else if constexpr (MODE == MODE_COUNT) {
+							if (own) ++mycount;
+						} else {
+							kv[st][u] = v;
+							if (own) { ++mycount; atomicOr(&s_cbm[slot >> 6], 1ull << (slot & 63u)); }
+							else ks[st][u] = 0xFFFFFFFFu;
+						}
+					}
+				}
+			}
+			if constexpr (MODE == MODE_DIGEST) {
+				d_cnt += mycount; d_sum += mysum;
+				if (sk.row_nnz) {
+					const unsigned long long rc = wave_reduce_sum((unsigned long long)mycount); const double rs = wave_reduce_sum(mysum);
+					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+				}
+				lds_barrier();                                      // claims done before the next cell accumulates
+			} else if constexpr (MODE == MODE_COUNT) {
+				const uint32_t wc = (uint32_t)wave_reduce_sum((unsigned long long)mycount);
+				if (lane == 0 && wc) atomicAdd(&s_count, wc);
+				lds_barrier();
+				if (tid == 0) { sk.segcount[seg] = s_count; s_count = 0; }
+				lds_barrier();
+			} else {
+				lds_barrier();                                      // claimed-column bitmap complete
+				if (wv == 0) {
+					uint32_t run = 0;
+#pragma unroll
+					for (int x = 0; x < NWORD / 64; ++x) {
+						const uint32_t cnt = (uint32_t)__popcll(s_cbm[x * 64 + lane]);
+						const uint32_t inc2 = wave_inclusive_scan_u32(cnt);
+						s_cpre[x * 64 + lane] = run + inc2 - cnt;
+						run += (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
+					}
+					if (lane == 0) s_cpre[NWORD] = run;
+				}
+				lds_barrier();
+				const int64_t o = sk.segoff[seg];
+#pragma unroll
+				for (int st = 0; st < MAXST; ++st) {
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						const uint32_t slot = ks[st][u];
+						if (slot < (uint32_t)W) {
+							const uint32_t wd = slot >> 6;
+							const uint32_t rank = s_cpre[wd] + (uint32_t)__popcll(s_cbm[wd] & ((1ull << (slot & 63u)) - 1ull));
+							sk.out_i[o + rank] = rowid;
+							sk.out_j[o + rank] = (int32_t)(wbase + slot);
+							sk.out_v[o + rank] = kv[st][u];
+						}
+					}
+				}
+				if (tid == 0) sk.segactual[seg] = s_cpre[NWORD];
+				lds_barrier();
+				for (int q = tid; q < NWORD; q += NT) s_cbm[q] = 0ull;
+				lds_barrier();
+			}
+		}
+		for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;     // (every wave is past its last lookup: the cell loop ends with a barrier)
+	}
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
+}
+
 // ====================================================================== holes (cancellation in STORE)
 
 __global__ void k_seg_holes(const uint32_t *segcount, const uint32_t *segactual, uint32_t nseg, unsigned long long *holes, const uint32_t *err)
@@ -1986,8 +2564,12 @@ struct Heavy {
 	uint32_t *xb[NCLS] = {};         // XCD part boundaries per class
 	int W = 8192;
 	uint32_t cell_cap = CELL_CAP_DEFAULT, dense_min = DENSE_MIN_DEFAULT;
-	TileBases tb{};
+	TileBases tb{};                  // hash tiles
 	uint32_t ntile = 0, ntcell = 0;
+	TileBases tb2{};                 // direct tiles (k_direct_tiles)
+	uint32_t ntile2 = 0, ntcell2 = 0;
+	uint32_t direct_min = 0;
+	bool tiles2 = false;
 	bool coo = false;                // the tiles also serve a STORE launch
 	unsigned long long clsprod[NCLS] = {};
 	uint32_t *wptr = nullptr;        // window-major copy of B (dense cells): row pointer per window ...
@@ -1999,6 +2581,36 @@ struct Heavy {
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
+	if (hv.ntile && hv.tiles2) {
+		const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;
+		static int per_cu2 = 0;
+		if (!per_cu2) {
+			int nb = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash_tiles2<MODE>, TILE2_NT, 0) != hipSuccess || nb < 1) nb = 1;
+			per_cu2 = nb;
+		}
+		const unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)(c->num_cu * per_cu2));
+#ifdef SPSAMD_STAMPS
+		SinkParams sk2 = sk;
+		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
+		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
+		k_hash_tiles2<MODE><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
+		{
+			std::vector<unsigned long long> h((size_t)grid * 12);
+			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipStreamSynchronize(c->stream));
+			double sum[12] = {};
+			for (unsigned g = 0; g < grid; ++g) for (int i = 0; i < 12; ++i) sum[i] += (double)h[(size_t)g * 12 + i];
+			static const char *nm[12] = {"pre", "expand", "tables+pf", "insert", "Bwait", "pf-next", "emit", "Bwait2", "tiles", "cells", "-", "-"};
+			fprintf(stderr, "k_hash_tiles2 stamps (mean cycles per workgroup, grid %u):", grid);
+			for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.4g", nm[i], sum[i] / grid);
+			fprintf(stderr, "\n");
+		}
+#else
+		k_hash_tiles2<MODE><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+#endif
+		SPS_LAUNCH_CHECK();
+	} else
 	if (hv.ntile) {
 		static int per_cu = 0;
 		if (!per_cu) {
@@ -2007,7 +2619,38 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 			per_cu = nb;
 		}
 		unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)(c->num_cu * per_cu));
+#ifdef SPSAMD_STAMPS
+		SinkParams sk2 = sk;
+		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
+		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
+		k_hash_tiles<MODE><<<dim3(grid), dim3(TILE_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, ep, sk2);
+		{
+			std::vector<unsigned long long> h((size_t)grid * 12);
+			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipStreamSynchronize(c->stream));
+			double sum[12] = {};
+			for (unsigned g = 0; g < grid; ++g) for (int i = 0; i < 12; ++i) sum[i] += (double)h[(size_t)g * 12 + i];
+			static const char *nm[12] = {"pre", "Bwait", "expand_load", "expand_batch", "products", "Bwait2", "segbcast", "emit", "tiles", "cells", "-", "-"};
+			fprintf(stderr, "k_hash_tiles stamps (mean cycles per workgroup, grid %u):", grid);
+			for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.4g", nm[i], sum[i] / grid);
+			fprintf(stderr, "\n");
+		}
+#else
 		k_hash_tiles<MODE><<<dim3(grid), dim3(TILE_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, ep, sk);
+#endif
+		SPS_LAUNCH_CHECK();
+	}
+	if (hv.ntile2) {
+		RowMeta m2 = m;
+		m2.btup = hv.btw;
+		const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;
+		if (hv.W == 8192) {
+			const unsigned grid = std::min<unsigned>(hv.ntile2, (unsigned)c->num_cu * 2u);
+			k_direct_tiles<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.tb2.tiles, hv.ntile2, hv.tb2.tcells, m2, hv.wptr, hv.nrowb, narrow, ep, sk);
+		} else {
+			const unsigned grid = std::min<unsigned>(hv.ntile2, (unsigned)c->num_cu);
+			k_direct_tiles<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.tb2.tiles, hv.ntile2, hv.tb2.tcells, m2, hv.wptr, hv.nrowb, narrow, ep, sk);
+		}
 		SPS_LAUNCH_CHECK();
 	}
 	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], hv.xb[0], m, hv.bwin, hv.nwin1, ep, sk);
@@ -2079,7 +2722,7 @@ static float elapsed(hipEvent_t a, hipEvent_t b)
 
 // Heavy rows: window index of B, per-row window histogram, counting pass of the cell grouping.
 static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
-	uint32_t extra, uint32_t *nseg)
+	uint32_t extra, uint32_t *nseg, bool ordered)
 {
 	hipStream_t st = c->stream;
 	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
@@ -2119,20 +2762,33 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
 	hv.tb.enabled = !c->tune.no_tiles;
-	hv.tb.pb = hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB;
-	hv.tb.ntc = c->arena.get<uint32_t>(hv.n); hv.tb.ntl = c->arena.get<uint32_t>(hv.n);
-	hv.tb.tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); hv.tb.tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
-	fill_zero(c, hv.tb.ntc, hv.n * sizeof(uint32_t)); fill_zero(c, hv.tb.ntl, hv.n * sizeof(uint32_t));
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, hv.tb);
+	hv.tiles2 = !ordered && !c->tune.tiles_v1;      // second-generation tile kernel (no ascending-k variant)
+	hv.tb.by_items = hv.tiles2 ? 1 : 0;
+	hv.tb.pb = hv.tiles2 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+	hv.tb2.by_items = 1;
+	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
+	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
+	hv.tb2.enabled = hv.tb.enabled && !c->tune.no_wmajor && !ordered && hv.direct_min < hv.dense_min;
+	hv.tb2.pb = (uint32_t)hv.W;      // items of a direct tile: one bit each in a W-bit bitmap
+	for (TileBases *t : {&hv.tb, &hv.tb2}) {
+		t->ntc = c->arena.get<uint32_t>(hv.n); t->ntl = c->arena.get<uint32_t>(hv.n);
+		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
+		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
+	}
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min});
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntl, hv.tb.tlbase, hv.n);
+	scan_exclusive_u32_u32(c, hv.tb2.ntc, hv.tb2.tcbase, hv.n);
+	scan_exclusive_u32_u32(c, hv.tb2.ntl, hv.tb2.tlbase, hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
 	hv.ntcell = read_back(c, hv.tb.tcbase + hv.n);
 	hv.ntile = read_back(c, hv.tb.tlbase + hv.n);
+	hv.ntcell2 = read_back(c, hv.tb2.tcbase + hv.n);
+	hv.ntile2 = read_back(c, hv.tb2.tlbase + hv.n);
 	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
-	if (hv.ncell[CLS_DENSE] && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
+	if ((hv.ncell[CLS_DENSE] || hv.ntile2) && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
 }
 
 // Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.
@@ -2145,19 +2801,23 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
 	hv.tb.tcells = c->arena.get<TCell>(hv.ntcell ? hv.ntcell : 1);
 	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, hv.tb);
+	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
+	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min});
 	SPS_LAUNCH_CHECK();
-	if (hv.ntile > 1) {
-		uint32_t nd = hv.ntile;
+	for (int kd = 0; kd < 2; ++kd) {
+		TileBases &t = kd ? hv.tb2 : hv.tb;
+		const uint32_t nd = kd ? hv.ntile2 : hv.ntile;
+		if (nd < 2) continue;
 		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
 		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
-		k_tile_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, nd, k0);
+		k_tile_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(t.tiles, nd, k0);
 		SPS_LAUNCH_CHECK();
 		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, wbits);
 		Tile *sorted = c->arena.get<Tile>(nd);
-		k_gather_tiles<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.tb.tiles, where ? p1 : p0, nd, sorted);
+		k_gather_tiles<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(t.tiles, where ? p1 : p0, nd, sorted);
 		SPS_LAUNCH_CHECK();
-		hv.tb.tiles = sorted;
+		t.tiles = sorted;
 	}
 	for (int k = 0; k < NCLS; ++k) {
 		uint32_t nd = hv.ncell[k];
@@ -2268,6 +2928,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
 	SPS_LAUNCH_CHECK();
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
+#ifdef SPSAMD_ABLATIONS
+	SPS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl), &c->tune.dbg, sizeof(int), 0, hipMemcpyHostToDevice, st));
+#endif
 	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val,
 		c->tune.emit_path,
 #ifdef SPSAMD_ABLATIONS
@@ -2284,7 +2947,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	Heavy hv;
 	hv.n = bins.count[8];
 	hv.coo = coo;
-	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg);
+	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0);
 	ep.wshift = hv.W == 8192 ? 13u : 14u;
 	uint32_t *segbase = nullptr;
 	int64_t nsegs = 0;
@@ -2305,7 +2968,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		k_row_cells<<<dim3(grid_for(nb)), dim3(256), 0, st>>>(bins.rows + bins.off[5 + k], nb, rl.beg, rl.id, rprod, segbase, mc.cells[k]);
 		SPS_LAUNCH_CHECK();
 	}
-	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3] + hv.ntcell;
+	res->cells_hash = (uint64_t)hv.ncell[0] + hv.ncell[1] + hv.ncell[2] + hv.ncell[3] + hv.ntcell + hv.ntcell2;
 	res->cells_dense = hv.ncell[CLS_DENSE];
 	res->window = hv.n ? (uint32_t)hv.W : 0u;
 	res->products_dense = hv.clsprod[CLS_DENSE];
