@@ -79,7 +79,7 @@ struct Tuning {
 	int emit_path = 0;           // 0 auto | 1 no bitmap rank | 2 bitonic only
 	int light_path = 0;          // 0 auto | 1 generic k_light only
 	int no_wmajor = 0;           // 1: dense cells read the row-major B through bwin (no window-major copy)
-	int tiles_v1 = 0;            // 1: first-generation hash-tile kernel
+	int tiles_v1 = 0;            // tile kernel of the hash-class cells: 0 auto, 1 first generation, 2 hash tiles v2, 3 bitmap rank
 	int direct_min = 0;          // 0: default; products above which one window of a tile row becomes a direct cell (>= dense_min: never)
 	int bwin_budget_mb = 0;      // 0: default cap of the dense window index before the compact index is used
 #ifdef SPSAMD_ABLATIONS

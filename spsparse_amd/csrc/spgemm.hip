@@ -1442,7 +1442,7 @@ constexpr int CLS_DENSE = NCLS - 1;
 constexpr uint32_t CELL_CAP = 4096;      // largest hash cell (T = 8192)
 constexpr uint32_t CELL_CAP_DEFAULT = 2048;      // greedy grouping target of the hash cells (measured best on R-MAT scale-20)
 constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // a single window above this becomes a dense cell
-constexpr uint32_t DIRECT_MIN_DEFAULT = 256;     // a single window of a tile row above this becomes a direct cell
+constexpr uint32_t DIRECT_MIN_DEFAULT = 1536;    // a single window of a tile row above this becomes a direct cell (measured: below ~1000 the hash tile wins)
 __device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 1536 ? 1 : (prods <= 2048 ? 2 : 3)); }
 
 struct CellBases { uint32_t *base[NCLS]; };      // per heavy row: first cell index in each class list
@@ -1453,7 +1453,7 @@ struct CellLists { Cell *list[NCLS]; };
 struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; int by_items; };
 // Two kinds of tile: [0] hash cells (ranges of sparse windows, LDS hash table), [1] direct cells (ONE window holding
 // more than direct_min products, dense window accumulator with claim-by-exchange emission: k_direct_tiles)
-struct TileKinds { TileBases k[2]; uint32_t direct_min; };
+struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; };    // span_cap: most windows one tile cell may cover (0: any)
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
@@ -1544,7 +1544,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 			cur = c; start = last = w;
 			flush();
 		} else if (c > 0) {
-			if (cur + c > cell_cap) flush();
+			if (cur + c > cell_cap || (cur && tileable && tk.span_cap && w - start >= tk.span_cap)) flush();
 			if (!cur) start = w;
 			cur += c; last = w;
 		}
@@ -2268,6 +2268,276 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
 }
 
+// ---- bitmap tiles: cells are ranges [wa, wb) of at most BM_WORDS * 64 columns, accumulated by RANK ---------
+// The cell's products are looked up and read once and stay in registers (<= 3 items of R tuples per lane):
+//   1. every product sets the bit of its column in a bitmap over the cell's column range (ds_or, no return value);
+//   2. the bitmap's words are prefix-summed (popcounts): the RANK of a column = set bits below it;
+//   3. every product adds its value to acc[rank] (ds_add_f64) and notes its column in colof[rank];
+//   4. acc[0 .. distinct) IS the cell's output in ascending column order: emitted and zeroed, bitmap words cleared.
+// No probing, no compare-and-swap chains, no list of occupied slots, no sort for the COO order; the structural count of
+// a cell (COUNT launch) is just the popcount total.  LDS: bitmap 16 KB + prefix 4 KB + acc 16 KB + colof 8 KB.
+constexpr int BM_NT = 512;
+constexpr int BM_WORDS = 2048;           // bitmap words: 131072 columns = 16 windows of 8192 (8 of 16384)
+constexpr int BM_MAXOUT = 2048;          // distinct columns of a cell (<= its products <= TILE_T / 2)
+constexpr int BM_ITEMS = 8192;           // items per tile
+
+template <int MODE>
+__global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
+	const uint32_t *bwin, uint32_t nwin1, uint32_t narrow, EmitParams ep, SinkParams sk)
+{
+	constexpr int NT = BM_NT, NW = NT / 64, R = DENSE_R;
+	constexpr int NWORD = BM_ITEMS / 64;
+	constexpr int MAXST = 3;
+	constexpr int WPT = BM_WORDS / NT;       // bitmap words per thread in the scan (4)
+	__shared__ unsigned long long bm[BM_WORDS];
+	__shared__ uint16_t bpre[BM_WORDS];
+	__shared__ double acc[BM_MAXOUT];
+	__shared__ uint32_t colof[BM_MAXOUT];
+	__shared__ TileX<NT, NWORD> X;
+	__shared__ uint32_t s_wtot[2][NW];
+	__shared__ uint32_t s_scan[NW + 1];
+	__shared__ unsigned long long s_u64[2 * NW];
+	__shared__ double s_f64[NW];
+
+	const unsigned tid = threadIdx.x, lane = lane_id();
+	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
+	for (int q = tid; q < BM_WORDS; q += NT) bm[q] = 0ull;
+	for (int q = tid; q < BM_MAXOUT; q += NT) acc[q] = 0.0;
+	for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;
+	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;
+	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;
+	uint32_t flip = 0, sflip = 0;
+	const char *bbase = reinterpret_cast<const char *>(m.btup);
+#ifdef SPSAMD_STAMPS
+	unsigned long long st_[12] = {}; unsigned long long st_t = clock64();
+#endif
+
+	const uint32_t stride = gridDim.x;
+	const uint32_t tlast = ntile - 1;
+	Tile rec1 = tiles[min(blockIdx.x, tlast)];
+	Tile rec2 = tiles[min(blockIdx.x + stride, tlast)];
+	uint32_t nlo, nlen, nseg_, nw_; double na;
+	{
+		const uint32_t L = rec1.end - rec1.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		const uint32_t c = tid >> lsh, ei = tid & ((1u << lsh) - 1u);
+		const bool act = c < rec1.ncells && ei < L;
+		const uint32_t ec = rec1.beg + (ei < L ? ei : 0u);
+		const TCell tc = tcells[rec1.first + (c < rec1.ncells ? c : 0u)];
+		const uint32_t *bw = bwin + (uint64_t)(uint32_t)m.acol[ec] * nwin1;
+		const uint32_t lo = bw[tc.wa], hi = bw[tc.wb];
+		na = m.aval[ec];
+		nlo = lo; nlen = act ? hi - lo : 0u; nseg_ = tc.seg; nw_ = (uint32_t)tc.wa | ((uint32_t)tc.wb << 16);
+	}
+	__syncthreads();
+	for (uint32_t ti = blockIdx.x; ti < ntile; ti += stride) {
+		const Tile tile = rec1;
+		const uint32_t lo = nlo, len = nlen, myseg = nseg_, myw = nw_; const double a = na;
+		const uint32_t L = tile.end - tile.beg;
+		uint32_t lsh = 0;
+		while ((1u << lsh) < L) ++lsh;
+		lsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsh);
+		const int32_t rowid = tile.rowid;
+		const double a_scale = row_scale(ep, rowid);
+		rec1 = rec2;
+		rec2 = tiles[min(ti + 2 * stride, tlast)];
+		const bool has_next = ti + stride < ntile;
+		const uint32_t nL = rec1.end - rec1.beg;
+		uint32_t nsh = 0;
+		while ((1u << nsh) < nL) ++nsh;
+		const uint32_t nc = tid >> nsh, nei = tid & ((1u << nsh) - 1u);
+		const bool nact = has_next && nc < rec1.ncells && nei < nL;
+		const uint32_t nec = rec1.beg + (nei < nL ? nei : 0u);
+		const TCell ntc = tcells[rec1.first + (nc < rec1.ncells ? nc : 0u)];
+		const int32_t nk = m.acol[nec];
+		na = m.aval[nec];
+
+		uint32_t total, nzc;
+		STAMP_COUNT(10);
+		STAMP(0);
+		tile_expand(X, lsh, tile.ncells, lo, len, a, myseg, myw, flip, &total, &nzc);
+		STAMP(1);
+		{
+			const uint32_t *bw = bwin + (uint64_t)(uint32_t)nk * nwin1;
+			const uint32_t nlo_ = bw[ntc.wa], nhi_ = bw[ntc.wb];
+			nlo = nlo_; nlen = nact ? nhi_ - nlo_ : 0u; nseg_ = ntc.seg; nw_ = (uint32_t)ntc.wa | ((uint32_t)ntc.wb << 16);
+		}
+		if (total == 0 || nzc == 0) {                               // uniform; cannot happen for real tiles
+			if (MODE != MODE_DIGEST) for (uint32_t c = tid; c < tile.ncells; c += NT) { if (MODE == MODE_COUNT) sk.segcount[X.cellseg[c]] = 0; else sk.segactual[X.cellseg[c]] = 0; }
+			continue;
+		}
+		TileTab<NWORD / 64> tab;
+		tile_tables(X, tab);
+
+		// first block of cell 0, prefetched like every later cell's
+		uint32_t pbp, pnv; double pav;
+		tile_lookup(X, tab, nzc, (X.cellI[0] >> 6) + wv, X.cellI[1], pbp, pnv, pav);
+		BPiece ppiece = fetch_piece(bbase, pbp, narrow);
+		STAMP(0);
+		for (uint32_t c = 0; c < tile.ncells; ++c) {
+			STAMP_COUNT(11);
+			const uint32_t i0 = X.cellI[c], i1 = X.cellI[c + 1];
+			const uint32_t seg = X.cellseg[c];
+			const uint32_t nblk = (i1 - i0) >> 6;
+			const uint32_t wab = X.cellw[c];
+			const uint32_t colbase = (wab & 0xFFFFu) << ep.wshift;
+			const uint32_t nwords = ((wab >> 16) - (wab & 0xFFFFu)) << (ep.wshift - 6);      // bitmap words of the cell's column range
+			if ((nblk > (uint32_t)(MAXST * NW) || nwords > (uint32_t)BM_WORDS) && tid == 0) atomicOr(sk.err, 2u);   // never: k_cells bounds both
+			// ---- 1. products into registers, column bits into the bitmap
+			uint32_t krel[MAXST][R]; double kval[MODE == MODE_COUNT ? 1 : MAXST][MODE == MODE_COUNT ? 1 : R];
+#pragma unroll
+			for (int st = 0; st < MAXST; ++st) {
+#pragma unroll
+				for (int u = 0; u < R; ++u) krel[st][u] = 0xFFFFFFFFu;
+				const uint32_t bl = (uint32_t)st * NW + wv;
+				if (st > 0 && bl >= nblk) continue;                         // wave-uniform (step 0's piece is prefetched)
+				uint32_t nv; double av; BPiece piece;
+				if (st == 0) { nv = bl < nblk ? pnv : 0u; av = pav; piece = ppiece; }
+				else {
+					uint32_t bp;
+					tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
+					piece = fetch_piece(bbase, bp, narrow);
+				}
+#pragma unroll
+				for (int u = 0; u < R; ++u) {
+					if ((uint32_t)u < nv) {
+						const uint32_t rel = piece.w[3 * u] - colbase;
+						krel[st][u] = rel;
+						if constexpr (MODE != MODE_COUNT) kval[st][u] = av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
+						atomicOr(&bm[rel >> 6], 1ull << (rel & 63u));
+					}
+				}
+			}
+			STAMP(2);
+			lds_barrier();                                          // the bitmap is complete
+			STAMP(3);
+			// the next cell's first block: lookup and B request issued now, consumed after this cell is done
+			if (c + 1 < tile.ncells) {                              // uniform
+				tile_lookup(X, tab, nzc, (i1 >> 6) + wv, X.cellI[c + 2], pbp, pnv, pav);
+				ppiece = fetch_piece(bbase, pbp, narrow);
+			}
+			// ---- 2. rank prefix of the bitmap words: thread t owns words [WPT t, WPT t + WPT)
+			uint32_t wcnt[WPT], mine = 0;
+#pragma unroll
+			for (int x = 0; x < WPT; ++x) {
+				const uint32_t w = tid * WPT + x;
+				wcnt[x] = w < nwords ? (uint32_t)__popcll(bm[w]) : 0u;
+				mine += wcnt[x];
+			}
+			const uint32_t inc = wave_inclusive_scan_u32(mine);
+			if (lane == 63) s_wtot[sflip][wv] = inc;
+			STAMP(4);
+			lds_barrier();
+			STAMP(5);
+			uint32_t base = 0, distinct = 0;
+#pragma unroll
+			for (int q = 0; q < NW; ++q) { const uint32_t t = s_wtot[sflip][q]; if (q < (int)wv) base += t; distinct += t; }
+			sflip ^= 1u;
+			distinct = (uint32_t)__builtin_amdgcn_readfirstlane((int)distinct);
+			{
+				uint32_t run = base + inc - mine;
+#pragma unroll
+				for (int x = 0; x < WPT; ++x) {
+					const uint32_t w = tid * WPT + x;
+					if (w < nwords) bpre[w] = (uint16_t)run;
+					run += wcnt[x];
+				}
+			}
+			if (MODE == MODE_COUNT && !ep.sk_pos) {
+				// structural count: the distinct columns (scalek absent: every column is allowed); clean up and go on
+				if (tid == 0) sk.segcount[seg] = distinct;
+#pragma unroll
+				for (int x = 0; x < WPT; ++x) { const uint32_t w = tid * WPT + x; if (w < nwords && wcnt[x]) bm[w] = 0ull; }
+				lds_barrier();
+				continue;
+			}
+			STAMP(4);
+			lds_barrier();                                          // prefix visible
+			STAMP(5);
+			// ---- 3. accumulate by rank
+#pragma unroll
+			for (int st = 0; st < MAXST; ++st) {
+#pragma unroll
+				for (int u = 0; u < R; ++u) {
+					const uint32_t rel = krel[st][u];
+					if (rel != 0xFFFFFFFFu) {
+						const uint32_t w = rel >> 6;
+						const uint32_t rank = (uint32_t)bpre[w] + (uint32_t)__popcll(bm[w] & ((1ull << (rel & 63u)) - 1ull));
+						if constexpr (MODE != MODE_COUNT) atomicAdd(&acc[rank], kval[st][u]);
+						colof[rank] = rel;
+					}
+				}
+			}
+			STAMP(6);
+			lds_barrier();                                          // acc[0 .. distinct) holds the cell's sums in column order
+			STAMP(7);
+			// ---- 4. emit in order, clean the accumulator and the bitmap words that were used
+			if constexpr (MODE == MODE_DIGEST) {
+				unsigned long long cnt = 0; double vs = 0;
+				for (uint32_t i = tid; i < distinct; i += NT) {
+					const uint32_t rel = colof[i];
+					double v = acc[i];
+					acc[i] = 0.0;
+					bm[rel >> 6] = 0ull;
+					const int32_t col = (int32_t)(colbase + rel);
+					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, col, v, &v);
+					if (ok) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+				}
+				d_cnt += cnt; d_sum += vs;
+				if (sk.row_nnz) {
+					const unsigned long long rc = wave_reduce_sum(cnt); const double rs = wave_reduce_sum(vs);
+					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+				}
+			} else if constexpr (MODE == MODE_COUNT) {
+				// scalek present: count the allowed columns
+				uint32_t cnt = 0;
+				for (uint32_t i = tid; i < distinct; i += NT) {
+					const uint32_t rel = colof[i];
+					bm[rel >> 6] = 0ull;
+					if (col_allowed(ep, (int32_t)(colbase + rel))) ++cnt;
+				}
+				uint32_t tot;
+				block_exclusive_scan<uint32_t, NT>(cnt, s_scan, &tot);
+				if (tid == 0) sk.segcount[seg] = tot;
+			} else {
+				// COO: rank order IS column order; sums that cancelled to exactly 0 (or columns scalek drops) leave no
+				// tuple, so the survivors are compacted with one more scan
+				const int64_t o = sk.segoff[seg];
+				uint32_t run = 0;
+				for (uint32_t ibase = 0; ibase < distinct; ibase += NT) {
+					const uint32_t i = ibase + tid;
+					bool ok = false; double v = 0; uint32_t rel = 0;
+					if (i < distinct) {
+						rel = colof[i];
+						v = acc[i];
+						acc[i] = 0.0;
+						bm[rel >> 6] = 0ull;
+						ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v);
+					}
+					uint32_t tot;
+					const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);
+					if (ok) {
+						sk.out_i[o + run + ex] = rowid;
+						sk.out_j[o + run + ex] = (int32_t)(colbase + rel);
+						sk.out_v[o + run + ex] = v;
+					}
+					run += tot;
+				}
+				if (tid == 0) sk.segactual[seg] = run;
+			}
+			STAMP(8);
+			lds_barrier();                                          // clean: the next cell may set bits
+			STAMP(9);
+		}
+		for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;     // (every wave is past its last lookup)
+	}
+#ifdef SPSAMD_STAMPS
+	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
+#endif
+	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
+}
+
 // ---- direct tiles: ONE window per cell, dense accumulator, claim-by-exchange emission ----------------------
 // A direct cell holds more than direct_min products in one window of a tile row -- too few to pay for k_dense's scan
 // of all W accumulator slots.  It
@@ -2569,7 +2839,8 @@ struct Heavy {
 	TileBases tb2{};                 // direct tiles (k_direct_tiles)
 	uint32_t ntile2 = 0, ntcell2 = 0;
 	uint32_t direct_min = 0;
-	bool tiles2 = false;
+	int tiles2 = 0;
+	uint32_t span_cap = 0;
 	bool coo = false;                // the tiles also serve a STORE launch
 	unsigned long long clsprod[NCLS] = {};
 	uint32_t *wptr = nullptr;        // window-major copy of B (dense cells): row pointer per window ...
@@ -2581,7 +2852,30 @@ struct Heavy {
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
-	if (hv.ntile && hv.tiles2) {
+	if (hv.ntile && hv.tiles2 == 0) {
+		const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;
+		const unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)c->num_cu * 2u);
+#ifdef SPSAMD_STAMPS
+		SinkParams sk2 = sk;
+		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
+		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
+		k_bm_tiles<MODE><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
+		{
+			std::vector<unsigned long long> h((size_t)grid * 12);
+			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+			SPS_HIP(hipStreamSynchronize(c->stream));
+			double sum[12] = {};
+			for (unsigned g = 0; g < grid; ++g) for (int i = 0; i < 12; ++i) sum[i] += (double)h[(size_t)g * 12 + i];
+			static const char *nm[12] = {"pre", "expand", "bits", "B", "scan", "B", "rank-add", "B", "emit", "B", "tiles", "cells"};
+			fprintf(stderr, "k_bm_tiles stamps (mean cycles per workgroup, grid %u):", grid);
+			for (int i = 0; i < 12; ++i) fprintf(stderr, " %s %.4g", nm[i], sum[i] / grid);
+			fprintf(stderr, "\n");
+		}
+#else
+		k_bm_tiles<MODE><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+#endif
+		SPS_LAUNCH_CHECK();
+	} else if (hv.ntile && hv.tiles2 == 2) {
 		const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;
 		static int per_cu2 = 0;
 		if (!per_cu2) {
@@ -2758,13 +3052,18 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	}
 	if (c->tune.cell_cap >= 64 && c->tune.cell_cap <= (int)CELL_CAP) hv.cell_cap = (uint32_t)c->tune.cell_cap;
 	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
-	if (hv.dense_min < hv.cell_cap) hv.dense_min = hv.cell_cap;
+	// (a window between dense_min and cell_cap products becomes a dense cell; smaller ones are grouped up to cell_cap)
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
 	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
 	hv.tb.enabled = !c->tune.no_tiles;
-	hv.tiles2 = !ordered && !c->tune.tiles_v1;      // second-generation tile kernel (no ascending-k variant)
-	hv.tb.by_items = hv.tiles2 ? 1 : 0;
-	hv.tb.pb = hv.tiles2 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+	// tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles, second generation.
+	// Only the first generation has the ascending-k (ordered) variant.
+	// Default (measured, R-MAT scale 20): the hash tiles for the digest sink (42.6 vs 46.8 ms), the bitmap tiles for
+	// the COO sink, whose COUNT launch is then a popcount and whose STORE launch needs no sort (210 vs 225 ms).
+	hv.tiles2 = ordered ? 1 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : (c->tune.tiles_v1 == 3 ? 0 : (hv.coo ? 0 : 2))));
+	hv.tb.by_items = hv.tiles2 != 1 ? 1 : 0;
+	hv.tb.pb = hv.tiles2 != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+	hv.span_cap = hv.tiles2 == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	hv.tb2.by_items = 1;
 	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
 	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
@@ -2775,7 +3074,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
 		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
 	}
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min});
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap});
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
@@ -2803,7 +3102,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
 	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
 	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min});
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap});
 	SPS_LAUNCH_CHECK();
 	for (int kd = 0; kd < 2; ++kd) {
 		TileBases &t = kd ? hv.tb2 : hv.tb;
