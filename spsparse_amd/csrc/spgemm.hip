@@ -31,6 +31,7 @@
 #include "devutil.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -438,6 +439,190 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 	}
 	}
 	if (MODE == MODE_DIGEST) digest_flush<256>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
+}
+
+// ---- all rows light: the direct kernel ---------------------------------------------------------------
+// When (longest row of op(A)) x (longest row of op(B)) <= 64 every output row has at most 64 products and the
+// whole symbolic phase (per-tuple B row lengths, their prefix, row classes, row lists, the 12-byte B copy) is
+// skipped: this kernel walks the dense row pointer of op(A) and reads everything itself.  The regular stencils
+// (BASELINE cfg3 and cfg5) are the case it is for.  Per wave G = 64 / S rows, S slots each:
+//   A lanes (s < La) read (k, a) and the bounds of B row k; a DPP scan numbers the products of the row;
+//   a product's A lane is the running maximum of markers the A lanes drop at their first product's slot (one LDS
+//   write per A TUPLE, a DPP max-scan per product) and its (start, offset, a) come over the LDS crossbar (bpermute);
+//   products are put in (column, A position) order by rank -- a 32-bit key (column << log2 S | A position) where the
+//   column count allows, S broadcast compares -- and summed head by head in that order: ascending k, the order of
+//   the reference's `sum += a*b` (multiply_sparse.hpp:219-236), so the values are bit-identical.
+template <int S, int MODE, bool K64>
+__global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const uint32_t *aptr, const int32_t *acol, const double *aval,
+	const uint32_t *bptr, const int32_t *bcol, const double *bval, EmitParams ep, SinkParams sk, unsigned long long *prod_count)
+{
+	constexpr int G = 64 / S;
+	constexpr int LOGS = S == 8 ? 3 : (S == 16 ? 4 : (S == 32 ? 5 : 6));
+	typedef typename std::conditional<K64, uint64_t, uint32_t>::type key_t;
+	constexpr key_t NOKEY = (key_t)~(key_t)0;
+	__shared__ uint32_t s_mark[4][64];
+	__shared__ key_t s_key[4][64];
+	__shared__ key_t s_key2[4][64];
+	__shared__ double s_val2[4][64];
+	__shared__ unsigned long long s_u64[8];
+	__shared__ double s_f64[4];
+
+	const unsigned w = wave_id(), lane = lane_id();
+	const unsigned g = lane / S, s = lane % S;
+	unsigned long long d_cnt = 0, d_hash = 0, n_prod = 0; double d_sum = 0.0;
+	const uint32_t nvb = (nrow + 4u * G - 1u) / (4u * G);
+	// Software pipeline over the row groups of this workgroup: the chain row pointer -> A tuple -> B row bounds ->
+	// B tuples is four dependent global loads; its first three links are fetched one link per round ahead
+	// (branch-free: clamped indices, results masked), so that a round only waits for its B tuples.
+	const uint32_t stride = gridDim.x;
+	auto row_of = [&](uint32_t vb_) { return (vb_ * 4u + w) * G + g; };
+	auto load_bounds = [&](uint32_t vb_, uint32_t &b_, uint32_t &e_) {
+		const uint32_t r_ = row_of(vb_);
+		const bool ok = vb_ < nvb && r_ < nrow;
+		const uint32_t rc = ok ? r_ : 0u;
+		b_ = aptr[rc]; e_ = aptr[rc + 1];
+		if (ep.si_pos) {                                             // scalei: absent or zero -> the row is skipped
+			const int32_t q = ep.si_pos[rc];
+			if (q < 0 || ep.si_val[q] == 0) e_ = b_;
+		}
+		if (!ok) e_ = b_;
+	};
+	auto load_tuple = [&](uint32_t b_, uint32_t e_, int32_t &k_, double &a_, bool &v_) {
+		const uint32_t e = b_ + s;
+		v_ = e < e_;
+		const uint32_t ec = v_ ? e : (b_ < e_ ? b_ : 0u);                // any valid tuple (A has at least one)
+		k_ = acol[ec]; a_ = aval[ec];
+	};
+	auto load_brow = [&](int32_t k_, bool v_, uint32_t &lo_, uint32_t &len_) {
+		const uint32_t l0 = bptr[k_], l1 = bptr[k_ + 1];
+		lo_ = l0; len_ = v_ ? l1 - l0 : 0u;
+	};
+	uint32_t beg1, end1, beg2, end2;                                // bounds of round +1, +2
+	int32_t k1; double a1; bool v1;                                 // A tuple of round +1
+	uint32_t lo0, len0; double a0;                                  // B row bounds of this round
+	{
+		uint32_t b0, e0; int32_t k0; bool v0;
+		load_bounds(blockIdx.x, b0, e0);
+		load_bounds(blockIdx.x + stride, beg1, end1);
+		load_tuple(b0, e0, k0, a0, v0);
+		load_brow(k0, v0, lo0, len0);
+		load_tuple(beg1, end1, k1, a1, v1);
+	}
+	for (uint32_t vb = blockIdx.x; vb < nvb; vb += stride) {
+		const uint32_t r = row_of(vb);
+		const bool has_row = r < nrow;
+		const uint32_t lo = lo0, len = len0; const double a = a0;
+		// prefetches for the next rounds (consumed after this round's work)
+		load_bounds(vb + 2 * stride, beg2, end2);
+		uint32_t nlo, nlen;
+		load_brow(k1, v1, nlo, nlen);
+		const double na = a1;
+		int32_t k2; double a2; bool v2;
+		const uint32_t inc = group_inclusive_scan_u32<S>(len, s);
+		const uint32_t ex = inc - len;
+		const uint32_t P = (uint32_t)__shfl((int)inc, (int)(g * S + S - 1), 64);       // products of the row (<= S)
+		// ---- product slot -> its A lane: markers + running maximum
+		s_mark[w][lane] = 0u;
+		if (len) s_mark[w][g * S + ex] = s + 1u;                     // (LDS traffic of one wave is in order)
+		wave_lds_sync();
+		uint32_t mk = s_mark[w][lane];
+		wave_lds_sync();
+		{
+			int x = (int)mk, t;
+			t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); if (s >= 1) x = max(x, t);
+			t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); if (s >= 2) x = max(x, t);
+			t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); if (s >= 4) x = max(x, t);
+			if (S >= 16) { t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); if (s >= 8) x = max(x, t); }
+			if (S >= 32) { t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); if (s >= 16) x = max(x, t); }
+			if (S >= 64) { t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); if (s >= 32) x = max(x, t); }
+			mk = (uint32_t)x;
+		}
+		const bool act = s < P;                                      // then mk >= 1
+		const int src = (int)(g * S + (mk ? mk - 1u : 0u));
+		const uint32_t slo = (uint32_t)__shfl((int)lo, src, 64), sex = (uint32_t)__shfl((int)ex, src, 64);
+		const double sa = __shfl(a, src, 64);
+		// ---- product, key (column, A position)
+		key_t key = NOKEY;
+		double prod = 0.0;
+		if (act) {
+			const uint32_t bp = slo + (s - sex);
+			const int32_t col = bcol[bp];
+			prod = sa * bval[bp];
+			key = (key_t)(((key_t)(uint32_t)col << LOGS) | (key_t)(mk - 1u));
+		}
+		s_key[w][lane] = key;
+		s_key2[w][lane] = NOKEY;
+		wave_lds_sync();
+		// ---- rank inside the row's S slots (keys are unique), scatter to sorted order
+		uint32_t rank = 0;
+#pragma unroll
+		for (int j = 0; j < S; ++j) rank += (s_key[w][g * S + j] < key) ? 1u : 0u;
+		if (act) { s_key2[w][g * S + rank] = key; s_val2[w][g * S + rank] = prod; }
+		wave_lds_sync();
+		// ---- segmented sum in ascending k (sequential, like `sum += a*b`)
+		const key_t mykey = s_key2[w][lane];
+		const bool act2 = mykey != NOKEY;
+		const uint32_t mycol = (uint32_t)(mykey >> LOGS);
+		const bool head = act2 && (s == 0 || (uint32_t)(s_key2[w][lane - 1] >> LOGS) != mycol);
+		double sum = 0.0;
+		if (head) sum += s_val2[w][lane];                            // 0 + a*b, as `sum = 0; sum += ...` (multiply_sparse.hpp:219)
+		bool more = head;
+		for (int t = 1; t < S; ++t) {
+			bool cont = false;
+			if (more && (int)s + t < S) {
+				const key_t nk = s_key2[w][lane + t];
+				cont = nk != NOKEY && (uint32_t)(nk >> LOGS) == mycol;
+			}
+			if (!__any(cont)) break;
+			if (cont) sum += s_val2[w][lane + t]; else more = false;
+		}
+		wave_lds_sync();                                             // the next round overwrites the arrays
+		// ---- emit
+		const int32_t rowid = (int32_t)r;
+		double value = 0;
+		const bool out = head && emit_value(ep, row_scale(ep, rowid), (int32_t)mycol, sum, &value);
+		const uint64_t bal = __ballot(out);
+		const uint64_t gmask = S == 64 ? bal : ((bal >> (g * S)) & ((1ull << (S & 63)) - 1ull));
+		if (s == 0) n_prod += P;
+		if (MODE == MODE_COUNT) {
+			if (has_row && s == 0) sk.segcount[r] = (uint32_t)__popcll(gmask);
+		} else if (MODE == MODE_STORE) {
+			if (has_row) {
+				if (out) {
+					const uint32_t rk = (uint32_t)__popcll(gmask & ((1ull << s) - 1ull));
+					const int64_t o = sk.segoff[r] + rk;
+					sk.out_i[o] = rowid; sk.out_j[o] = (int32_t)mycol; sk.out_v[o] = value;
+				}
+				if (s == 0) sk.segactual[r] = (uint32_t)__popcll(gmask);
+			}
+		} else {
+			if (sk.row_nnz) {
+				double rs = out ? value : 0.0;
+#pragma unroll
+				for (int d = S / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d, 64);
+				if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; }
+			}
+			if (out) { ++d_cnt; d_hash += mix64((uint32_t)rowid, mycol); d_sum += value; }
+		}
+		// rotate the pipeline: the A tuple of round +2 needs the bounds loaded at the top of THIS round
+		load_tuple(beg2, end2, k2, a2, v2);
+		lo0 = nlo; len0 = nlen; a0 = na;
+		k1 = k2; a1 = a2; v1 = v2;
+	}
+	n_prod = wave_reduce_sum(n_prod);
+	if (lane == 0 && n_prod) atomicAdd(prod_count, n_prod);
+	if (MODE == MODE_DIGEST) digest_flush<256>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
+}
+
+// longest row of a dense row pointer
+__global__ void k_max_rowlen(const uint32_t *ptr, uint64_t nrow, uint32_t *out)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = r < nrow ? ptr[r + 1] - ptr[r] : 0u;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+	// (same-address atomics serialise: only a wave that would raise the maximum issues one)
+	if (lane_id() == 0 && v > *(volatile uint32_t *)out) atomicMax(out, v);
 }
 
 // ====================================================================== hash cells (LDS hash accumulator)
@@ -3149,6 +3334,98 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	}
 }
 
+template <int S, int MODE>
+static void launch_light_direct(spsamd_ctx *c, uint32_t nrow, const uint32_t *aptr, const int32_t *acol, const double *aval,
+	const uint32_t *bptr, const ConMat &B, bool k64, const EmitParams &ep, const SinkParams &sk, unsigned long long *pc)
+{
+	const unsigned per = 4u * (64u / S);
+	const unsigned grid = std::min<unsigned>((nrow + per - 1) / per, (unsigned)c->num_cu * 8u * 4u);
+	if (k64) k_light_direct<S, MODE, true><<<dim3(grid), dim3(256), 0, c->stream>>>(nrow, aptr, acol, aval, bptr, B.col, B.val, ep, sk, pc);
+	else k_light_direct<S, MODE, false><<<dim3(grid), dim3(256), 0, c->stream>>>(nrow, aptr, acol, aval, bptr, B.col, B.val, ep, sk, pc);
+	SPS_LAUNCH_CHECK();
+}
+
+template <int MODE>
+static void launch_light_direct_s(spsamd_ctx *c, uint32_t maxp, uint32_t nrow, const uint32_t *aptr, const int32_t *acol, const double *aval,
+	const uint32_t *bptr, const ConMat &B, bool k64, const EmitParams &ep, const SinkParams &sk, unsigned long long *pc)
+{
+	if (maxp <= 8) launch_light_direct<8, MODE>(c, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+	else if (maxp <= 16) launch_light_direct<16, MODE>(c, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+	else if (maxp <= 32) launch_light_direct<32, MODE>(c, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+	else launch_light_direct<64, MODE>(c, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+}
+
+// Every output row has at most `maxp` <= 64 products: one kernel, no symbolic phase (see k_light_direct).
+static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res, const uint32_t *aptr, const int32_t *acol, const double *aval,
+	const uint32_t *bptr, uint32_t maxp)
+{
+	hipStream_t st = c->stream;
+	const ConMat &A = a.A, &B = a.B;
+	const uint32_t nrow = (uint32_t)A.nrow;
+	EmitParams ep{a.C, a.si.present ? a.si.pos : nullptr, a.si.val, a.sk.present ? a.sk.pos : nullptr, a.sk.val, c->tune.emit_path,
+#ifdef SPSAMD_ABLATIONS
+		c->tune.dbg,
+#endif
+		0u, B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u, 0};
+	const bool k64 = ep.ncolbits + 6u > 32u;                        // (column << log2 S | A position) does not fit 32 bits
+	SinkParams sk{};
+	sk.err = c->arena.get<uint32_t>(1);
+	fill_zero(c, sk.err, sizeof(uint32_t));
+	unsigned long long *pc = c->arena.get<unsigned long long>(1);
+	fill_zero(c, pc, sizeof(unsigned long long));
+	SPS_HIP(hipEventRecord(c->ev[2], st));
+	SPS_HIP(hipEventRecord(c->ev[3], st));
+	if (a.sink_kind != SPSAMD_SINK_COO) {
+		DigestSlot *slots = c->arena.get<DigestSlot>(DIGEST_SLOTS + 1);
+		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
+		sk.digest = slots;
+		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) {
+			c->rowstat_n.ensure(A.nrow * sizeof(long long));
+			c->rowstat_s.ensure(A.nrow * sizeof(double));
+			fill_zero(c, c->rowstat_n.p, A.nrow * sizeof(long long));
+			fill_zero(c, c->rowstat_s.p, A.nrow * sizeof(double));
+			sk.row_nnz = (long long *)c->rowstat_n.p;
+			sk.row_sum = (double *)c->rowstat_s.p;
+			res->row_nnz = (const int64_t *)sk.row_nnz;
+			res->row_sum = sk.row_sum;
+		}
+		launch_light_direct_s<MODE_DIGEST>(c, maxp, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS, sk.err);
+		SPS_LAUNCH_CHECK();
+		SPS_HIP(hipEventRecord(c->ev[4], st));
+		DigestSlot d = read_back(c, slots + DIGEST_SLOTS);
+		res->nnz = d.count; res->hash = d.hash; res->sum = d.sum;
+	} else {
+		// COO: one segment per row of op(A) (empty rows included): count, scan, store
+		const size_t nsegs = nrow;
+		uint32_t *segcount = c->arena.get<uint32_t>(nsegs + 1);
+		uint32_t *segactual = c->arena.get<uint32_t>(nsegs + 1);
+		int64_t *segoff = c->arena.get<int64_t>(nsegs + 1);
+		sk.segcount = segcount; sk.segoff = segoff; sk.segactual = segactual;
+		launch_light_direct_s<MODE_COUNT>(c, maxp, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+		scan_exclusive_u32_i64(c, segcount, segoff, nsegs);
+		const int64_t total = read_back(c, segoff + nsegs);
+		OutSet &os = c->out[c->cur_out];
+		os.i.ensure((size_t)total * sizeof(int32_t));
+		os.j.ensure((size_t)total * sizeof(int32_t));
+		os.v.ensure((size_t)total * sizeof(double));
+		sk.out_i = (int32_t *)os.i.p; sk.out_j = (int32_t *)os.j.p; sk.out_v = (double *)os.v.p;
+		fill_zero(c, pc, sizeof(unsigned long long));
+		launch_light_direct_s<MODE_STORE>(c, maxp, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
+		SPS_HIP(hipEventRecord(c->ev[4], st));
+		// the counting launch evaluated the same sums (ascending k, deterministic): the counts are exact, no holes
+		res->nnz = (uint64_t)total;
+		res->idx0 = sk.out_i; res->idx1 = sk.out_j; res->val = sk.out_v;
+	}
+	res->products = read_back(c, pc);
+	res->rows_light = nrow; res->products_light = res->products; res->tuples_light = A.nnz;
+	SPS_HIP(hipEventRecord(c->ev[7], st));
+	SPS_HIP(hipEventSynchronize(c->ev[7]));
+	res->ms_symbolic = elapsed(c->ev[1], c->ev[2]);
+	res->ms_numeric = elapsed(c->ev[2], c->ev[7]);
+	res->ms_light = elapsed(c->ev[3], c->ev[4]);
+}
+
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 {
 	hipStream_t st = c->stream;
@@ -3157,12 +3434,8 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	if (A.nnz == 0 || B.nnz == 0) return;           // empty product (also SURVEY Appendix A.3)
 
 	SPS_HIP(hipEventRecord(c->ev[1], st));
-	// ---- row structure of A (dim_beginnings) and dense row pointer of B (+ sentinel row for scalej)
-	RowList rl;
-	dim_beginnings(c, A, &rl);
 	const uint32_t extra = a.sj.present ? 1u : 0u;
 	uint32_t *bptr = dense_rowptr(c, B, extra);
-
 	const int32_t *acol = A.col;
 	const double *aval = A.val;
 	if (a.sj.present) {
@@ -3172,6 +3445,25 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		SPS_LAUNCH_CHECK();
 		acol = acol2; aval = aval2;
 	}
+	// ---- all rows light?  (longest A row) x (longest B row) <= 64: the direct kernel, no symbolic phase
+	if (!c->tune.light_path) {
+		const bool same = A.row == B.row && A.col == B.col && A.nnz == B.nnz && A.nrow == B.nrow;
+		const uint32_t *aptr = same ? bptr : dense_rowptr(c, A, 0);
+		uint32_t *mx = c->arena.get<uint32_t>(2);
+		fill_zero(c, mx, 2 * sizeof(uint32_t));
+		k_max_rowlen<<<dim3(grid_for(A.nrow)), dim3(256), 0, st>>>(aptr, A.nrow, mx);
+		SPS_LAUNCH_CHECK();
+		if (!same) { k_max_rowlen<<<dim3(grid_for(B.nrow)), dim3(256), 0, st>>>(bptr, B.nrow, mx + 1); SPS_LAUNCH_CHECK(); }
+		struct { uint32_t a, b; } hm = read_back(c, (const decltype(hm) *)mx);
+		if (same) hm.b = hm.a;
+		if ((uint64_t)hm.a * hm.b <= 64 && A.nrow < (uint64_t(1) << 32)) {
+			spgemm_all_light(c, a, res, aptr, acol, aval, bptr, (uint32_t)((uint64_t)hm.a * hm.b));
+			return;
+		}
+	}
+	// ---- row structure of A (dim_beginnings)
+	RowList rl;
+	dim_beginnings(c, A, &rl);
 
 	// ---- symbolic: products per A tuple, per row, bins
 	uint32_t *elen = c->arena.get<uint32_t>(A.nnz);
