@@ -17,9 +17,10 @@ One step = one pass of the hot path over the whole synthetic matrix:
           one GPU (R-MAT scale-23) and cfg2 into the COO sink with the
           PCIe-inclusive host delivery rate.  --no-other-configs skips them.
   N > 1   strong scaling on the same matrix: every rank owns a contiguous row
-          block of the raw tuples; a step = consolidate the own block,
-          all-to-allv of the needed B row panels (RCCL), multiply the block
-          against its panel.  C stays row partitioned (no reduction).  The block
+          block of the raw tuples; a step = spsamd_dist_multiply (C ABI):
+          consolidate the own block, exchange the needed B row panels with
+          grouped ncclSend / ncclRecv (RCCL), multiply the block against its
+          panel.  C stays row partitioned (no reduction).  The block
           boundaries are setup: a per-row cost estimate first, then --calibrate
           rounds of (run the step, gather every rank's local time, move the
           boundaries so the measured times come out equal); they are fixed
@@ -299,7 +300,7 @@ def main():
         return t0, t1, tv
 
     def consolidated(coo):
-        """device consolidate -> torch tensors (row, col, val)"""
+        """device consolidate -> torch tensors (row, col, val)   (setup only)"""
         r = ctx.consolidate(coo, 0)
         m = int(r.nnz)
         o0 = torch.empty(m, dtype=torch.int32, device=dev)
@@ -324,31 +325,27 @@ def main():
     bounds = sd.product_balanced_bounds(cost, world)
     del c0, c1, cv, P, rowlen, cost
 
+    # the step itself lives behind the C ABI (spsamd_dist_multiply): consolidate the own block, exchange the needed
+    # B row panels with grouped ncclSend / ncclRecv, multiply.  The communicator is the library's own, created
+    # from a unique id that rank 0 hands out through torch.distributed.
+    if args.rehearse_gloo:
+        dd = capi.Dist(ctx, rank, world, transport=sd.host_transport(ctx, world))
+    else:
+        uid = [capi.Dist.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dd = capi.Dist(ctx, rank, world, unique_id=uid[0])
+
     def take_block(b):
         keep = (raw0 >= b[rank]) & (raw0 < b[rank + 1])
         return raw0[keep].contiguous(), raw1[keep].contiguous(), rawv[keep].contiguous()
 
     def run_block(blk):
-        """One step on this rank's block; also returns the time of its local part (consolidate +
-        multiply, without the exchange, where a rank also waits for the slowest one)."""
+        """One step on this rank's block; also returns the device time of its local part (the block product,
+        without the exchange, where a rank also waits for the slowest one)."""
         blk0, blk1, blkv = blk
-        t_a = time.perf_counter()
-        a0, a1, av = consolidated(capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n)))
-        torch.cuda.synchronize()
-        t_b = time.perf_counter()
-        if args.rehearse_gloo:
-            h0, h1, hv = a0.cpu(), a1.cpu(), av.cpu()
-            p0, p1, pv, remote = sd.exchange_b_panels(h1, h0, h1, hv, bounds_now[0], n)
-            p0, p1, pv = p0.to(dev), p1.to(dev), pv.to(dev)
-        else:
-            p0, p1, pv, remote = sd.exchange_b_panels(a1, a0, a1, av, bounds_now[0], n)
-        Ab = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
-        Bp = capi.device_coo(p0.data_ptr(), p1.data_ptr(), pv.data_ptr(), p0.numel(), (n, n), sort0=0)
-        torch.cuda.synchronize()
-        t_c = time.perf_counter()
-        res = ctx.multiply(Ab, Bp, sink=capi.SINK_DIGEST)
-        t_d = time.perf_counter()
-        return res, remote, ((t_b - t_a) + (t_d - t_c)) * 1e3
+        Ab = capi.device_coo(blk0.data_ptr(), blk1.data_ptr(), blkv.data_ptr(), blk0.numel(), (n, n))
+        res, st = dd.multiply(Ab, None, bounds_now[0], sink=capi.SINK_DIGEST)
+        return res, int(st.remote_tuples), float(res.ms_total)
 
     # ... then corrected by measurement: run the step, gather every rank's local time, move the
     # boundaries so that the measured times come out equal (sd.rebalance_bounds), repeat.
@@ -403,6 +400,7 @@ def main():
                         [r[0] for r in results], remote_total, calib,
                         "%d row blocks (per-row cost estimate, then %d measure/rebalance rounds) + all-to-allv of B row panels" % (world, len(calib)))
         print(json.dumps(line), flush=True)
+    dd.close()
     ctx.close()
     dist.destroy_process_group()
     finish()

@@ -245,6 +245,49 @@ int spsamd_sorted_permutation(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uin
  */
 int spsamd_dim_beginnings(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uint64_t *beginnings_host, size_t *count);
 
+/* ---- multi-GPU: A sharded by contiguous row blocks, one rank per GPU ----
+ * The reference has no counterpart.  Output row i depends only on row i of op(A) and the B rows
+ * {k : A(i,k) != 0} (the reference's own loop structure, multiply_sparse.hpp:192): every rank multiplies its
+ * row block of A with the panel of B rows it needs, fetched with ONE exchange step (grouped ncclSend / ncclRecv
+ * over RCCL: the all-to-allv of needed B row panels); C stays row partitioned, there is no reduction.
+ */
+typedef struct spsamd_dist spsamd_dist;
+
+/* Optional transport replacing the built-in RCCL one (tests: gloo / MPI through host memory).  All-to-allv of
+ * device buffers: send[p] (sendbytes[p] bytes) goes to rank p, recvbytes[p] bytes from rank p arrive in recv[p].
+ * The buffers are complete when it is called and must be complete when it returns. */
+typedef int (*spsamd_alltoallv_fn)(void *user, const void *const *send, const size_t *sendbytes,
+	void *const *recv, const size_t *recvbytes, int world, void *hip_stream);
+
+typedef struct {
+	uint64_t block_nnz_a;         /* consolidated tuples of this rank's A block */
+	uint64_t panel_tuples;        /* tuples of the B panel this rank multiplied with */
+	uint64_t remote_tuples;       /* ... of which received from other ranks */
+	uint64_t sent_tuples;         /* tuples this rank sent to other ranks */
+	float ms_exchange;            /* consolidate + masks + pack + exchange, before the block product (HIP events) */
+	float pad_;
+} spsamd_dist_stats;
+
+/* 128 bytes identifying a new RCCL communicator (ncclGetUniqueId): call on one rank, hand to all (MPI, a file,
+ * torch.distributed ...), then spsamd_dist_create(..., unique_id, ...) on every rank. */
+int spsamd_dist_unique_id(char id[128]);
+/* One of: unique_id (the library creates its communicator with ncclCommInitRank), nccl_comm (an ncclComm_t of
+ * the caller, borrowed), or transport (+ transport_user).  ctx: this rank's context (its device and stream). */
+int spsamd_dist_create(spsamd_dist **out, spsamd_ctx *ctx, int rank, int world, const char *unique_id,
+	void *nccl_comm, spsamd_alltoallv_fn transport, void *transport_user);
+void spsamd_dist_destroy(spsamd_dist *d);
+/*
+ * One step.  A_block: this rank's row block of A -- raw COO tuples with GLOBAL indices, shape = the whole
+ * matrix's.  B_block: the tuples of B whose row lies in [b_bounds[rank], b_bounds[rank+1]), or NULL for
+ * A * A when the A blocks are cut at b_bounds too (the own A block then is the own B block).
+ * b_bounds: world + 1 ascending row boundaries of B's distribution over the inner dimension (0 .. inner).
+ * The result is this rank's rows of C in the sink of its context (digest: add the counts / hashes / sums of all
+ * ranks; COO: tuples with global indices).  Collective: every rank of the communicator must call it.
+ */
+int spsamd_dist_multiply(spsamd_dist *d, double C, const spsamd_coo *A_block, const spsamd_coo *B_block,
+	const uint64_t *b_bounds, int duplicate_policy, int zero_nan, int sink_kind, int sink_flags,
+	spsamd_result *result, spsamd_dist_stats *stats);
+
 /* ---- synthetic operands generated on the device (bench / tests) ----
  * Bit-identical to spsparse_amd/workloads.py.  Outputs are device arrays
  * owned by the caller (capacity >= the generator's tuple count). */

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 VARIANT = os.environ.get("SPSAMD_VARIANT", "")
 LIBDIR = os.path.join(HERE, "lib", VARIANT) if VARIANT else os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspsparse_amd.so")
-SOURCES = ["prims.hip", "consolidate.hip", "spgemm.hip", "workload.hip", "capi.hip"]
+SOURCES = ["prims.hip", "consolidate.hip", "spgemm.hip", "workload.hip", "capi.hip", "dist.hip"]
 HEADERS = ["internal.h", "devutil.h", "workload_common.h", os.path.join("..", "..", "include", "spsparse_amd.h")]
 # -ffp-contract=off: products and sums are rounded separately like the
 # reference's x86-64 build (`sum += a*b`, multiply_sparse.hpp:228,235).
@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -55,13 +55,23 @@ class Result(C.Structure):
                 ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64)]
 
 
+class DistStats(C.Structure):
+    _fields_ = [("block_nnz_a", C.c_uint64), ("panel_tuples", C.c_uint64), ("remote_tuples", C.c_uint64),
+                ("sent_tuples", C.c_uint64), ("ms_exchange", C.c_float), ("pad_", C.c_float)]
+
+
+# spsamd_alltoallv_fn: (user, send**, sendbytes*, recv**, recvbytes*, world, stream)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                           C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
+
 CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_size_t)
 
 # every symbol include/spsparse_amd.h declares
 SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsamd_ctx_reserve", "spsamd_version", "spsamd_ctx_set_tuning",
            "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_result_scatter_dense", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
            "spsamd_dim_beginnings", "spsamd_gen_rmat",
-           "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"]
+           "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d",
+           "spsamd_dist_unique_id", "spsamd_dist_create", "spsamd_dist_destroy", "spsamd_dist_multiply"]
 
 _lib = None
 
@@ -109,6 +119,12 @@ def load():
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     for name in ("spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spsamd_dist_unique_id.argtypes = [C.c_char_p]
+    L.spsamd_dist_create.argtypes = [P(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, ALLTOALLV_FN, C.c_void_p]
+    L.spsamd_dist_destroy.argtypes = [C.c_void_p]
+    L.spsamd_dist_destroy.restype = None
+    L.spsamd_dist_multiply.argtypes = [C.c_void_p, C.c_double, P(Coo), P(Coo), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       P(Result), P(DistStats)]
     _lib = L
     return L
 
@@ -256,3 +272,52 @@ class Context:
 
     def gen_aggregation3d(self, N, p0, p1, pv):
         self._check(self.L.spsamd_gen_aggregation3d(self.h, N, p0, p1, pv))
+
+
+class Dist:
+    """spsamd_dist: this rank's end of the row-block sharded multiply (one rank per GPU).
+
+    transport=None: the built-in RCCL transport; `unique_id` (128 bytes from Dist.unique_id() on one rank,
+    handed to every rank) creates its communicator.  transport=callable(send_ptrs, send_bytes, recv_ptrs,
+    recv_bytes, stream) replaces it (the tests route it through gloo on host copies)."""
+
+    @staticmethod
+    def unique_id():
+        L = load()
+        buf = C.create_string_buffer(128)
+        rc = L.spsamd_dist_unique_id(buf)
+        if rc != 0:
+            raise SpsamdError(rc, "spsamd_dist_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, unique_id=None, transport=None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._cb = ALLTOALLV_FN()
+        if transport is not None:
+            def cb(_user, send, sendb, recv, recvb, n, stream):
+                try:
+                    transport([send[p] for p in range(n)], [sendb[p] for p in range(n)],
+                              [recv[p] for p in range(n)], [recvb[p] for p in range(n)], stream)
+                    return 0
+                except Exception:                      # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLTOALLV_FN(cb)
+        h = C.c_void_p()
+        rc = ctx.L.spsamd_dist_create(C.byref(h), ctx.h, rank, world, unique_id, None, self._cb, None)
+        ctx._check(rc)
+        self.h = h
+
+    def multiply(self, A_block, B_block, b_bounds, C_=1.0, duplicate_policy=ADD, zero_nan=False, sink=SINK_DIGEST, flags=0):
+        res, stats = Result(), DistStats()
+        bb = (C.c_uint64 * len(b_bounds))(*[int(x) for x in b_bounds])
+        rc = self.ctx.L.spsamd_dist_multiply(self.h, float(C_), C.byref(A_block), None if B_block is None else C.byref(B_block),
+                                             bb, duplicate_policy, int(zero_nan), sink, flags, C.byref(res), C.byref(stats))
+        self.ctx._check(rc)
+        return res, stats
+
+    def close(self):
+        if self.h:
+            self.ctx.L.spsamd_dist_destroy(self.h)
+            self.h = None

@@ -121,7 +121,7 @@ static bool same_operand(const spsamd_coo *a, const spsamd_coo *b)
 
 // Shared body of the MM and MV entry points.  `what` names the right operand in
 // the inner-dimension message ("B" or "V", multiply_sparse.hpp:173,299).
-static int multiply_body(spsamd_ctx *c, double C,
+int spsamd::multiply_body(spsamd_ctx *c, double C,
 	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
 	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
 	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,

@@ -184,6 +184,14 @@ struct MultiplyArgs {
 };
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res);
 
+// Shared body of the MM and MV entry points (capi.hip); `arena_ready`: the caller has reset the workspace
+// and may hold operands in it (the distributed step does).
+int multiply_body(spsamd_ctx *c, double C,
+	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
+	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
+	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,
+	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready);
+
 // Select the output set the next result is written to: the current one unless a device operand lives in it.
 void pick_output_set(spsamd_ctx *c, const spsamd_coo *const *operands, int n);
 

@@ -1,6 +1,8 @@
-"""Multi-GPU SpGEMM: A sharded by contiguous row blocks, B's needed row panels
-redistributed with one all-to-allv (torch.distributed: RCCL over xGMI on the
-GPU box, gloo in the CPU tests).  No reduction: C stays row partitioned.
+"""Multi-GPU SpGEMM, the harness side: row-block boundaries (cost model, measured rebalancing) and test
+transports.  The STEP itself -- consolidate the own block, exchange the needed B row panels, multiply --
+is spsamd_dist_multiply behind the C ABI (csrc/dist.hip, grouped ncclSend / ncclRecv over RCCL);
+exchange_b_panels below is the same exchange in torch tensors, kept as the CPU model the gloo tests
+check the partition logic with.  No reduction anywhere: C stays row partitioned.
 
 The reference is single threaded and has no counterpart of this module
 (SURVEY.md section 8e).  Output row i of C depends only on row i of op(A) and
@@ -166,3 +168,30 @@ def reduce_digest(count, digest_sum, digest_hash, device, group=None):
     dist.all_reduce(flt, group=group)
     h = ((int(ints[2]) << 32) + int(ints[1])) % (1 << 64)
     return int(ints[0]), float(flt[0]), h
+
+
+def host_transport(ctx, world, group=None):
+    """An spsamd_alltoallv_fn for capi.Dist that moves the device buffers through host memory and a
+    torch.distributed all-to-all (gloo): lets several ranks share ONE GPU in the tests, where RCCL refuses
+    two ranks on a device.  Not a measurement path."""
+    import numpy as np
+
+    def xfer(send, sendb, recv, recvb, _stream):
+        ins = []
+        for p in range(world):
+            buf = np.empty(max(int(sendb[p]), 1), np.uint8)
+            if sendb[p]:
+                ctx.memcpy(buf.ctypes.data, send[p], int(sendb[p]))
+            ins.append(torch.from_numpy(buf[:int(sendb[p])]))
+        flat_in = torch.cat(ins) if ins else torch.empty(0, dtype=torch.uint8)
+        flat_out = torch.empty(int(sum(recvb)), dtype=torch.uint8)
+        dist.all_to_all_single(flat_out, flat_in, output_split_sizes=[int(x) for x in recvb],
+                               input_split_sizes=[int(x) for x in sendb], group=group)
+        out = flat_out.numpy()
+        o = 0
+        for p in range(world):
+            if recvb[p]:
+                chunk = np.ascontiguousarray(out[o:o + int(recvb[p])])
+                ctx.memcpy(recv[p], chunk.ctypes.data, int(recvb[p]))
+            o += int(recvb[p])
+    return xfer

@@ -397,6 +397,36 @@ def test_bench_two_ranks_on_one_gpu(wl_args):
     assert len(two["config"]["calibration_local_ms"]) == 2 and len(two["config"]["calibration_local_ms"][0]) == 2
 
 
+def test_dist_step_one_rank_rccl(ctx):
+    """spsamd_dist_multiply (C ABI) on a 1-rank RCCL communicator created from a unique id: the whole step --
+    consolidate the block, masks, pack, grouped ncclSend/ncclRecv to itself, panel, block product -- must give the
+    single-GPU digest; raw tuples with duplicates in, B = A and B != A."""
+    from spsparse_amd import capi
+    a = wl.rmat(13, seed=4)
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    cnt, ssum, h = orc.digest(*want[:3])
+    d = capi.Dist(ctx, 0, 1, unique_id=capi.Dist.unique_id())
+    try:
+        s, keep = capi.host_coo(*a)
+        res, st = d.multiply(s, None, [0, a[3][1]])
+        assert (res.nnz, res.hash) == (cnt, h) and abs(res.sum - ssum) <= REL * abs(ssum)
+        assert st.remote_tuples == 0 and st.panel_tuples == res.nnz_b and st.block_nnz_a == res.nnz_a
+        b = wl.rmat(13, seed=9)
+        B = orc.Mat(*b)
+        want2 = orc.multiply(A, B, rowwise=True, nthreads=8)
+        cnt2, ssum2, h2 = orc.digest(*want2[:3])
+        sb, keepb = capi.host_coo(*b)
+        res2, st2 = d.multiply(s, sb, [0, b[3][0]])
+        assert (res2.nnz, res2.hash) == (cnt2, h2) and abs(res2.sum - ssum2) <= REL * abs(ssum2)
+        # the COO sink through the same entry point: tuples with global indices, in order
+        res3, _ = d.multiply(s, sb, [0, b[3][0]], sink=capi.SINK_COO)
+        gi, gj, gv = ctx.fetch(res3)
+        _check((gi, gj, gv), want2)
+    finally:
+        d.close()
+
+
 def test_two_contexts_on_two_threads(ctx):
     """SURVEY 8b 'Threading': the library must be callable concurrently on different handles.
     Two host threads, one context (HIP stream, arena) each, multiply different operands at once."""
