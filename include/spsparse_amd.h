@@ -20,6 +20,17 @@
  *   - one context = one device + one HIP stream + one workspace; calls on
  *     different contexts may run concurrently from different host threads.
  *   - there is no CPU fallback: every compute entry point needs the GPU.
+ *
+ * Limits (each is an SPSAMD_EINVAL / SPSAMD_ENOMEM with a message, never a wrong result)
+ *   - indices int32, fewer than 2^31 tuples per operand (like the reference's int positions,
+ *     algorithm.hpp:419); one output row may hold at most 2^32-1 scalar products.
+ *   - rows with more than 4096 scalar products ("heavy" rows) are cut along column windows of 8192
+ *     columns (16384 above 2^21 columns): at most 2048 windows, i.e. op(B) may have at most 2^25 columns
+ *     when the product has a heavy row.  Products whose rows all stay at or below 4096 scalar products
+ *     have no column limit below 2^31.
+ *   - the heavy-row path keeps two dense indices of rows(op(B)) x (windows + 1) 32-bit positions in the
+ *     workspace (0.5 GB each for a 2^20-square matrix, 17 GB each at 2^23): SPSAMD_ENOMEM if the device
+ *     cannot hold them.
  */
 #ifndef SPSPARSE_AMD_H
 #define SPSPARSE_AMD_H
@@ -204,11 +215,12 @@ int spsamd_result_fetch(spsamd_ctx *ctx, const spsamd_result *result,
  * DenseAccum (accum.hpp:110-140) on the device: apply the tuples of a SINK_COO
  * result to a row-major dense matrix in device memory,
  *     dense[i * ld + j]  (op)=  v        per duplicate_policy
- * ADD sums into the existing entry, REPLACE overwrites it, LEAVE_ALONE writes
- * only where the entry is still exactly 0 (the first value stays).  The
- * reference's LEAVE_ALONE branch tests !isnan(oval) and then overwrites
- * (accum.hpp:129-131, SURVEY Appendix A.12: looks inverted); the documented
- * meaning of the policy (spsparse.hpp:19-23) is implemented instead.
+ * ADD sums into the existing entry, REPLACE overwrites it.  LEAVE_ALONE does what
+ * the reference's code does, on both sides of the boundary (this entry point and the
+ * host mirror in spsparse_amd/multiply.hpp): `if (!std::isnan(oval)) oval = val`
+ * (accum.hpp:128-130) -- the entry is overwritten unless it holds a NaN.  SURVEY
+ * Appendix A.12 notes that this looks inverted against the policy's documented
+ * meaning (spsparse.hpp:19-23); a drop-in keeps the behaviour callers get today.
  */
 int spsamd_result_scatter_dense(spsamd_ctx *ctx, const spsamd_result *result, double *dense_device, size_t ld,
 	int duplicate_policy);

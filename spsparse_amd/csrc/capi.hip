@@ -267,7 +267,7 @@ __global__ void k_scatter_dense(const int32_t *i, const int32_t *j, const double
 		double *p = dense + (size_t)i[t] * ld + (size_t)j[t];      // (i, j) is unique inside one result
 		if (policy == SPSAMD_ADD) *p += v[t];
 		else if (policy == SPSAMD_REPLACE) *p = v[t];
-		else if (*p == 0) *p = v[t];
+		else if (!(*p != *p)) *p = v[t];                          // LEAVE_ALONE exactly as accum.hpp:128-130 spells it: `if (!std::isnan(oval)) oval = val`
 	}
 }
 

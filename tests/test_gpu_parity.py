@@ -459,6 +459,38 @@ def test_two_contexts_on_two_threads(ctx):
     assert not errors, errors
 
 
+def test_heavy_row_capacity_limits_are_pinned(ctx):
+    """the windowed heavy-row path supports at most 2048 column windows of 16384 (ncol <= 2^25).  Beyond it
+    a product whose rows all stay at or below 4096 scalar products works as everywhere else, and one with a heavier
+    row is refused with SPSAMD_EINVAL and a message that names the limit (include/spsparse_amd.h, "Limits") -- never
+    a wrong result."""
+    from spsparse_amd import capi
+    ncol = (1 << 25) + 4096
+    rng = np.random.default_rng(5)
+    k = 6000
+    # B: k rows, one tuple each, columns spread over the whole (huge) range
+    bcols = np.sort(rng.choice(ncol, size=k, replace=False)).astype(np.int32)
+    B = orc.Mat(np.arange(k, dtype=np.int32), bcols, rng.random(k) + 0.5, (k, ncol))
+    # A: row 0 has 3000 tuples (3000 products: a mid row), row 1 has all 6000 (a heavy row)
+    light = orc.Mat(np.zeros(3000, np.int32), np.arange(3000, dtype=np.int32), rng.random(3000) + 0.5, (2, k))
+    got = _dev(ctx, light, B)
+    want = orc.multiply(light, B, rowwise=True)
+    _check(got, want)
+    assert got[3].rows_heavy == 0 and got[3].rows_mid == 1
+    heavy = orc.Mat(np.ones(k, np.int32), np.arange(k, dtype=np.int32), rng.random(k) + 0.5, (2, k))
+    with pytest.raises(capi.SpsamdError, match="column windows") as ei:
+        _dev(ctx, heavy, B)
+    assert ei.value.code == -2
+    # the same heavy row at 2^25 columns exactly is inside the limit
+    ncol2 = 1 << 25
+    bcols2 = np.sort(rng.choice(ncol2, size=k, replace=False)).astype(np.int32)
+    B2 = orc.Mat(np.arange(k, dtype=np.int32), bcols2, B.val, (k, ncol2))
+    got2 = _dev(ctx, heavy, B2)
+    want2 = orc.multiply(heavy, B2, rowwise=True)
+    _check(got2, want2)
+    assert got2[3].rows_heavy == 1 and got2[3].window == 16384
+
+
 def test_ablation_switch_is_not_in_the_shipped_library(monkeypatch):
     """SPSAMD_DBG (ablations that skip work and give wrong results on purpose) exists only in
     -DSPSAMD_ABLATIONS profiling builds.  With it set in the environment a fresh context still
@@ -743,6 +775,15 @@ def test_dense_accumulator_sink(ctx):
     assert np.allclose(got[:, :41], 2 * want, rtol=1e-12, atol=0) and not got[:, 41:].any()
     ctx.scatter_dense(res, dense.data_ptr(), 48, capi.REPLACE)
     assert np.allclose(dense.cpu().numpy()[:, :41], want, rtol=1e-12, atol=0)
+    # LEAVE_ALONE as the reference spells it (accum.hpp:128-130: `if (!std::isnan(oval)) oval = val`), the same on
+    # the device and in the host mirror: an entry is overwritten unless it holds a NaN
+    dense.fill_(7.0)
+    dense[0, :] = float("nan")
+    ctx.scatter_dense(res, dense.data_ptr(), 48, capi.LEAVE_ALONE)
+    got = dense.cpu().numpy()[:, :41]
+    hit = np.zeros((37, 41), dtype=bool)
+    hit[wi, wj] = True
+    assert np.all(np.isnan(got[0])) and np.allclose(got[1:][hit[1:]], want[1:][hit[1:]], rtol=1e-12, atol=0) and np.all(got[1:][~hit[1:]] == 7.0)
     with pytest.raises(capi.SpsamdError, match="leading dimension"):
         ctx.scatter_dense(res, dense.data_ptr(), 40)
 
