@@ -172,7 +172,7 @@ class Workload:
             rt = ctx.multiply(self.R, self.A, sink=capi.SINK_COO)
             rc = ctx.multiply(capi.result_operand(rt), self.R, tB="T", sink=capi.SINK_COO)
             return [rt, rc]
-        return [ctx.multiply(self.A, self.A, sink=self.sink)]
+        return [ctx.multiply(self.A, self.A, sink=self.sink, flags=getattr(self, "flags", 0))]
 
     def release(self):
         self.t = self.t2 = None

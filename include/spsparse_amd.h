@@ -105,6 +105,11 @@ typedef struct {
 #define SPSAMD_SINK_PERMUTE   4   /* COO, matrix result: emit (j, i, v) -- idx0 holds the column, idx1 the row, shape
                                    * swapped (PermuteAccum with perm {1,0}, accum.hpp:73-101; the tuples stay in
                                    * the order of C's rows, i.e. column-major for the permuted array) */
+#define SPSAMD_SINK_EXACT_PATTERN 8 /* the reference's INDEX SET at arrival-order speed: a sum that could be exactly
+                                   * zero in the reference's ascending-k order but not in arrival order (or the reverse) --
+                                   * |sum| within the rounding bound of its cell -- is re-evaluated in ascending k and that
+                                   * value decides (multiply_sparse.hpp:238) and is emitted; all other values stay within
+                                   * rounding (1e-12 relative) of the reference's */
 #define SPSAMD_SINK_ORDERED   2   /* every sum accumulated in ascending k like the reference's loop
                                    * (multiply_sparse.hpp:219-236): bit-identical values and zero drops on
                                    * any input, several times slower on rows with more than 64 products */

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--sink", default="digest")
+    ap.add_argument("--flags", type=int, default=0, help="sink flags (2 ordered, 8 exact pattern)")
     ap.add_argument("variants", nargs="*", default=["base"])
     args = ap.parse_args()
     import torch
@@ -36,6 +37,7 @@ def main():
                 k, v = kv.split("=")
                 ctx.set_tuning(k, int(v))
         w = bench.Workload(torch, capi, ctx, dev, args.workload, args.scale, args.grid, 1, args.sink)
+        w.flags = args.flags
         out, results = bench.run_workload(torch, w, args.steps, 1)
         st = out["stage_ms"]
         dig = out.get("digest", {}).get("hash"), tuple(out["nnz_c"])

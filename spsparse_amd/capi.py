@@ -19,6 +19,7 @@ SINK_COO, SINK_DIGEST = 1, 2
 SINK_ROWSTATS = 1
 SINK_ORDERED = 2
 SINK_PERMUTE = 4
+SINK_EXACT_PATTERN = 8
 
 ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE"}
 

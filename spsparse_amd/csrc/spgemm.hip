@@ -64,6 +64,7 @@ struct EmitParams {
 	uint32_t wshift;                                 // log2 of the column-window width of the heavy path (0 before it is chosen)
 	uint32_t ncolbits;                               // bits of the largest column index
 	int ordered;                                     // SPSAMD_SINK_ORDERED: ascending-k sums everywhere (bit-exact)
+	int pattern;                                     // SPSAMD_SINK_EXACT_PATTERN: sums that could be zero in only one summation order are re-evaluated in ascending k
 };
 
 // Ablation switches exist in profiling builds only (-DSPSAMD_ABLATIONS); the shipped library has none.
@@ -121,7 +122,8 @@ struct RowMeta {
 	const int32_t *acol;            // A tuples: inner index k
 	const double *aval;             // A tuples: value (already times scalej)
 	const uint32_t *bptr;           // B dense row pointer
-	const BTup *btup;               // B tuples, (col, val) interleaved
+	const BTup *btup;               // B tuples, (col, val) interleaved (a dense / direct launch points it at the window-major copy)
+	const BTup *btup_rm;            // ... always the row-major array (ordered re-evaluation)
 	const uint32_t *elo;            // A tuples: first B tuple of the selected row (bptr[k])
 	const uint32_t *elen;           // A tuples: length of the selected B row
 };
@@ -153,6 +155,68 @@ __device__ __forceinline__ bool col_allowed(const EmitParams &p, int32_t col)
 	int32_t q = p.sk_pos[col];
 	return q >= 0 && p.sk_val[q] != 0;
 }
+
+// ---- SPSAMD_SINK_EXACT_PATTERN: the index set of the reference, at arrival-order speed -----------------
+// Hash and dense cells add their products with LDS atomics in arrival order.  The VALUES then differ from the
+// reference's ascending-k sums by rounding only (north star: 1e-12), but the test `sum == 0` that decides whether a
+// tuple exists at all (multiply_sparse.hpp:238) can come out differently when terms cancel.  Two sums of the same n
+// terms in different orders differ by at most 2 (n-1) u S, S = sum of the |terms|, u = 2^-53; so only a slot whose
+// arrival-order sum is within that bound of zero can be zero in one order and not in the other.  Per cell the
+// kernels track S over ALL its products (an upper bound of every slot's own S) and whether products of both signs
+// occurred: a cell of one sign cannot cancel at all; otherwise a slot with |sum| <= 8 nseg u S_cell is re-evaluated
+// in ascending k straight from the operands (ordered_sum) and that exact value decides and is emitted.
+struct PatAcc { double sabs; uint32_t sor, sand; };              // per lane
+struct PatCell { double sabs; uint32_t sor, sand; uint32_t pad; };   // per cell, in LDS
+
+__device__ __forceinline__ void pat_init(PatAcc &a) { a.sabs = 0.0; a.sor = 0u; a.sand = 0xFFFFFFFFu; }
+__device__ __forceinline__ void pat_note(PatAcc &a, double p)
+{
+	a.sabs += fabs(p);
+	const uint32_t hi = (uint32_t)__double2hiint(p);
+	a.sor |= hi; a.sand &= hi;
+}
+// every wave adds its lanes' notes to the cell's record (call before the barrier that ends the accumulation)
+__device__ __forceinline__ void pat_publish(PatAcc &a, PatCell *cell)
+{
+	double sa = a.sabs;
+	uint32_t so = a.sor, sn = a.sand;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		sa += __shfl_xor(sa, d, 64);
+		so |= (uint32_t)__shfl_xor((int)so, d, 64);
+		sn &= (uint32_t)__shfl_xor((int)sn, d, 64);
+	}
+	if (lane_id() == 0) { atomicAdd(&cell->sabs, sa); atomicOr(&cell->sor, so); atomicAnd(&cell->sand, sn); }
+	pat_init(a);
+}
+__device__ __forceinline__ void pat_reset(PatCell *cell) { cell->sabs = 0.0; cell->sor = 0u; cell->sand = 0xFFFFFFFFu; }
+// |sum| at or below the returned bound: re-evaluate.  -1: the cell cannot cancel (one sign, all finite).
+__device__ __forceinline__ double pat_threshold(const PatCell *cell, uint32_t nseg)
+{
+	const double S = cell->sabs;
+	if (!(S < __longlong_as_double(0x7FF0000000000000ll))) return __longlong_as_double(0x7FF0000000000000ll);   // inf / NaN terms: every sum
+	if ((((cell->sor ^ cell->sand) >> 31) & 1u) == 0u) return -1.0;
+	return 8.0 * (double)nseg * 0x1p-53 * S;
+}
+// The reference's own sum for output (row of A tuples [beg, end), column col): ascending k, `sum += a*b`
+// (multiply_sparse.hpp:219-236).  One lane; used for the rare slots pat_threshold singles out.
+__device__ double ordered_sum(const RowMeta &m, uint32_t beg, uint32_t end, int32_t col)
+{
+	double sum = 0.0;
+	for (uint32_t e = beg; e < end; ++e) {
+		const int32_t k = m.acol[e];
+		uint32_t lo = m.bptr[k];
+		const uint32_t top = m.bptr[k + 1];
+		uint32_t hi = top;
+		while (lo < hi) {
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if (m.btup_rm[mid].col < col) lo = mid + 1; else hi = mid;
+		}
+		if (lo < top && m.btup_rm[lo].col == col) sum += m.aval[e] * btup_val(m.btup_rm[lo]);
+	}
+	return sum;
+}
+#define PAT_FIX(x, col_) do { if (PAT && !(fabs(x) > pthr)) (x) = ordered_sum(m, pbeg, pend, (col_)); } while (0)
 
 // Workgroup-wide digest accumulation: one set of atomics per workgroup, spread
 // over DIGEST_SLOTS accumulators so no address becomes a serial hot spot.
@@ -887,9 +951,9 @@ __device__ __forceinline__ uint32_t hash_slot(int32_t col)
 
 // Products [p0, p1) of the prepared batch starting at pb -> table.  U products per thread and
 // step: all B loads of a step are issued before the first insertion.
-template <int T, int NT, int PB, int MODE>
+template <int T, int NT, int PB, int MODE, bool PAT>
 __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t p0, uint32_t p1, uint32_t pb, const RowMeta &m,
-	int32_t *h_key, double *h_val, uint16_t *occ, uint32_t *s_nocc)
+	int32_t *h_key, double *h_val, uint16_t *occ, uint32_t *s_nocc, PatAcc &pat)
 {
 	constexpr int U = HASH_U;
 	const unsigned tid = threadIdx.x;
@@ -923,7 +987,7 @@ __device__ __forceinline__ void hash_products(const Expand<NT, PB> &X, uint32_t 
 					if constexpr ((T & (T - 1)) == 0) h = (h + 1) & (T - 1);
 					else h = h + 1 == (uint32_t)T ? 0u : h + 1;
 				}
-				if (MODE != MODE_COUNT) atomicAdd(&h_val[h], pv[u]);
+				if (MODE != MODE_COUNT) { atomicAdd(&h_val[h], pv[u]); if (PAT) pat_note(pat, pv[u]); }
 			}
 			slot_of[u] = h;
 			newmask[u] = __ballot(isnew);
@@ -1049,10 +1113,10 @@ __device__ __forceinline__ uint32_t *lds_radix_sort(uint32_t *a, uint32_t *b, ui
 struct DigestAcc { unsigned long long cnt, hash; double sum; };
 
 // Emit the occupied slots of the finished cell into the sink and clean them.
-template <int T, int NT, int MODE>
+template <int T, int NT, int MODE, bool PAT>
 __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t seg, const EmitParams &ep, const SinkParams &sk,
 	int32_t *h_key, double *h_val, const uint16_t *occ, uint64_t *s_sort, uint32_t *scr32, DigestAcc &d,
-	uint16_t *s_cnt, uint32_t colbase, uint32_t colbits)
+	uint16_t *s_cnt, uint32_t colbase, uint32_t colbits, const RowMeta &m, uint32_t pbeg, uint32_t pend, double pthr)
 {
 	const unsigned tid = threadIdx.x;
 	const double a_scale = row_scale(ep, rowid);
@@ -1069,7 +1133,9 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			uint32_t h = occ[i];
 			int32_t col = h_key[h];
 			double v;
-			if (emit_value(ep, a_scale, col, h_val[h], &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+			double x = h_val[h];
+			PAT_FIX(x, col);
+			if (emit_value(ep, a_scale, col, x, &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
 			h_key[h] = -1; h_val[h] = 0.0;
 		}
 		d.cnt += cnt; d.sum += vs;
@@ -1104,7 +1170,9 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 					const uint32_t h = occ[i];
 					const int32_t col = h_key[h];
 					double v = 0;
-					const bool ok = emit_value(ep, a_scale, col, h_val[h], &v);
+					double x = h_val[h];
+					PAT_FIX(x, col);
+					const bool ok = emit_value(ep, a_scale, col, x, &v);
 					h_key[h] = -1;
 					h_val[h] = ok ? v : 0.0;
 					if (ok) {
@@ -1146,7 +1214,9 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 				if (i < nocc) {
 					uint32_t h = occ[i]; col = h_key[h];
 					double v = 0;
-					ok = emit_value(ep, a_scale, col, h_val[h], &v);
+					double x = h_val[h];
+					PAT_FIX(x, col);
+					ok = emit_value(ep, a_scale, col, x, &v);
 					h_key[h] = -1;
 					h_val[h] = ok ? v : 0.0;
 				}
@@ -1178,7 +1248,9 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			if (i < nocc) {
 				h = occ[i]; col = h_key[h];
 				double v = 0;
-				ok = emit_value(ep, a_scale, col, h_val[h], &v);
+				double x = h_val[h];
+				PAT_FIX(x, col);
+				ok = emit_value(ep, a_scale, col, x, &v);
 				h_key[h] = -1;
 				h_val[h] = ok ? v : 0.0;
 			}
@@ -1220,7 +1292,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 
 // Persistent workgroups walk the cell list with a grid stride (the list is in window-major
 // order, so concurrently processed cells read the same column windows of B).
-template <int T, int NT, int MODE, bool WINDOWED>
+template <int T, int NT, int MODE, bool WINDOWED, bool PAT>
 __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, EmitParams ep, SinkParams sk)
 {
@@ -1232,11 +1304,14 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 	__shared__ Expand<NT, T / 2> X;
 	__shared__ uint32_t scr32[NT / 64 + 1];
 	__shared__ uint32_t s_nocc;
+	__shared__ PatCell s_pat;
 	__shared__ unsigned long long s_u64[2 * (NT / 64)];
 	__shared__ double s_f64[NT / 64];
 
 	const unsigned tid = threadIdx.x;
 	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
+	PatAcc pat; pat_init(pat);
+	if (tid == 0) pat_reset(&s_pat);
 	DigestAcc dacc{0, 0, 0.0};                                      // DIGEST, whole launch
 	uint32_t flip = 0;
 
@@ -1302,9 +1377,10 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 			if (!ABL(ep, 4)) expand_batch(X, 0, total, nzc);
 			if (ABL(ep, 1)) total = 0;
 			if (ep.ordered) hash_products_ordered<T, NT, T / 2, MODE>(X, 0, nzc, m, h_key, h_val, occ, &s_nocc);
-			else hash_products<T, NT, T / 2, MODE>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc);
+			else hash_products<T, NT, T / 2, MODE, PAT>(X, 0, total, 0, m, h_key, h_val, occ, &s_nocc, pat);
 			lds_barrier();
 		}
+		if (PAT) pat_publish(pat, &s_pat);                   // (complete at the barrier below)
 		// stage C of the pipeline: B segment bounds of the next cell's first chunk
 		{
 			uint32_t lo, hi;
@@ -1317,7 +1393,9 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		if (ABL(ep, 2)) nocc = 0;
 		uint32_t colbase = 0, colbits = ep.ncolbits;
 		if (WINDOWED) { colbase = wa << ep.wshift; colbits = ep.wshift + (wb - wa > 1 ? 32 - __builtin_clz(wb - wa - 1) : 0); }
-		hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
+		const double pthr = PAT ? pat_threshold(&s_pat, end - beg) : -1.0;
+		hash_emit<T, NT, MODE, PAT>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits, m, beg, end, pthr);
+		if (PAT) { lds_barrier(); if (tid == 0) pat_reset(&s_pat); }     // (the next cell's barrier orders the reset)
 	}
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, dacc.cnt, dacc.hash, dacc.sum, s_u64, s_f64);
 }
@@ -1354,12 +1432,15 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 	__shared__ Expand<NT, PB> X;
 	__shared__ uint32_t scr32[NT / 64 + 1];
 	__shared__ uint32_t s_nocc;
+	__shared__ PatCell s_pat;
 	__shared__ uint32_t cellP[TILE_MAXCELLS + 1];
 	__shared__ unsigned long long s_u64[2 * (NT / 64)];
 	__shared__ double s_f64[NT / 64];
 
 	const unsigned tid = threadIdx.x;
 	for (int q = tid; q < T; q += NT) { h_key[q] = -1; if (MODE != MODE_COUNT) h_val[q] = 0.0; }
+	PatAcc pat; pat_init(pat);
+	if (tid == 0) pat_reset(&s_pat);
 	DigestAcc dacc{0, 0, 0.0};
 	uint32_t flip = 0;
 #ifdef SPSAMD_STAMPS
@@ -1434,7 +1515,9 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 				// the cell's products [p0, p1) are whole segments (a segment belongs to one cell)
 				const uint32_t q0 = expand_lookup(X, p0, 0), q1 = expand_lookup(X, p1 - 1, 0) + 1;
 				hash_products_ordered<T, NT, PB, MODE>(X, q0, q1, m, h_key, h_val, occ, &s_nocc);
-			} else hash_products<T, NT, PB, MODE>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc);
+			} else if (ep.pattern) hash_products<T, NT, PB, MODE, true>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc, pat);
+			else hash_products<T, NT, PB, MODE, false>(X, p0, p1, 0, m, h_key, h_val, occ, &s_nocc, pat);
+			if (ep.pattern) pat_publish(pat, &s_pat);
 			STAMP(4);
 			lds_barrier();
 			STAMP(5);
@@ -1451,8 +1534,11 @@ __global__ __launch_bounds__(TILE_NT) void k_hash_tiles(const Tile *tiles, uint3
 				colbits = ep.wshift + (tcc.wb - tcc.wa > 1 ? 32 - __builtin_clz((uint32_t)(tcc.wb - tcc.wa) - 1u) : 0);
 			}
 			STAMP(6);
-			hash_emit<T, NT, MODE>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
+			const double pthr = ep.pattern ? pat_threshold(&s_pat, tile.end - tile.beg) : -1.0;
+			if (ep.pattern) hash_emit<T, NT, MODE, true>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits, m, tile.beg, tile.end, pthr);
+			else hash_emit<T, NT, MODE, false>(nocc, tile.rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits, m, tile.beg, tile.end, pthr);
 			STAMP(7);
+			if (ep.pattern) { lds_barrier(); if (tid == 0) pat_reset(&s_pat); }
 			lds_barrier();
 		}
 	}
@@ -1790,7 +1876,7 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 // are read as one 12 R-byte piece, and the sums go to the LDS accumulator with ds_add_f64.
 // Occupancy: 16 waves per CU (two 512-thread workgroups, or one of 1024) = 4 per SIMD, so the kernel
 // is held to 128 VGPRs (launch bound 4): a build that needs more silently halves the occupancy.
-template <int W, int NT, int MODE>
+template <int W, int NT, int MODE, bool PAT>
 __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *widx, uint64_t kstride, uint64_t wstride, uint32_t narrow, EmitParams ep, SinkParams sk)
 {
@@ -1808,6 +1894,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	__shared__ unsigned long long s_bmask[NWORD];
 	__shared__ uint32_t s_scrL[2][NW], s_scrN[2][NW];
 	__shared__ uint32_t s_wcnt[NW + 1];
+	__shared__ PatCell s_pat;
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
 
@@ -1818,6 +1905,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;    // uniform: the emitted value is the sum itself
 	const unsigned long long laneK = (unsigned long long)lane * 0x9E3779B97F4A7C15ull;
 	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;     // DIGEST, whole launch
+	PatAcc pat; pat_init(pat);
+	if (tid == 0) pat_reset(&s_pat);
 	uint32_t flip = 0;
 #ifdef SPSAMD_STAMPS
 	unsigned long long st_[12] = {}; unsigned long long st_t = clock64();
@@ -1876,6 +1965,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		}
 
 		STAMP_COUNT(8);
+		uint32_t pnseg = 0;                                         // non-empty segments of the cell (EXACT_PATTERN)
 		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
 			STAMP_COUNT(9);
 			// stage B for chunk c+1 (its k arrived during chunk c-1), stage A for chunk c+2
@@ -2002,7 +2092,11 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 						const uint32_t slot = (uint32_t)u < nv_ ? (ABL(ep, 64) ? (piece.w[3 * u] & (W - 1)) : piece.w[3 * u] - wbase) : (uint32_t)W + lane;
 						if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[slot] = av_; }          // no LDS accumulate
 						else if (MODE == MODE_COUNT) acc[slot] = 1.0;        // structural: touched
-						else atomicAdd(&acc[slot], av_ * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
+						else {
+							const double pv = av_ * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
+							atomicAdd(&acc[slot], pv);
+							if (PAT && (uint32_t)u < nv_) pat_note(pat, pv);
+						}
 					}
 				};
 				STAMP(4);
@@ -2037,6 +2131,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 				Q0 = run;
 				STAMP(5);
 			}
+			if (PAT) { pat_publish(pat, &s_pat); pnseg += nzc; }
 			lds_barrier();                                          // B3: segment tables and bitmap are free again
 			STAMP(6);
 			for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
@@ -2056,6 +2151,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		// Kept lean, it runs once per cell over all W slots: with C = 1 and no scale vectors the emitted value IS the
 		// sum (sum * 1 * 1 * 1, multiply_sparse.hpp:242, is the same bits), and the index hash of column J0 + lane is
 		// mix64's product evaluated as X0 + lane * K with the group's X0 kept in scalar registers.
+		const double pthr = PAT ? pat_threshold(&s_pat, pnseg) : -1.0;
+		const uint32_t pbeg = beg, pend = end;
 		double v[GPW];
 		uint64_t nzmask[GPW];
 		uint32_t wcount = 0;
@@ -2068,6 +2165,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			double x = acc[grp * 64 + lane];
 			acc[grp * 64 + lane] = 0.0;
 			bool ok;
+			if (MODE != MODE_COUNT && PAT) { if (!(fabs(x) > pthr)) x = ordered_sum(m, pbeg, pend, (int32_t)(wbase + grp * 64 + lane)); }
 			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, (int32_t)(wbase + grp * 64 + lane));
 			else if (plain) ok = x != 0;
 			else ok = emit_value(ep, a_scale, (int32_t)(wbase + grp * 64 + lane), x, &x);
@@ -2115,6 +2213,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			__syncthreads();                                        // s_wcnt is reused by the next cell
 		}
 		STAMP(7);
+		if (PAT) { lds_barrier(); if (tid == 0) pat_reset(&s_pat); }     // every thread has read the cell's record
 	}
 #ifdef SPSAMD_STAMPS
 	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
@@ -2273,7 +2372,7 @@ constexpr int TILE2_NT = 512;
 constexpr int TILE2_T = 4096;
 constexpr int TILE2_ITEMS = 8192;        // items per tile: bitmap of 128 words, two per lane
 
-template <int MODE>
+template <int MODE, bool PAT>
 __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, uint32_t narrow, EmitParams ep, SinkParams sk)
 {
@@ -2288,6 +2387,7 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 	__shared__ TileX<NT, NWORD> X;
 	__shared__ uint32_t scr32[NW + 1];
 	__shared__ uint32_t s_nocc;
+	__shared__ PatCell s_pat;
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
 
@@ -2297,6 +2397,8 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 	if (tid < 64) h_key[T + tid] = -1;
 	for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;
 	if (tid == 0) s_nocc = 0;
+	PatAcc pat; pat_init(pat);
+	if (tid == 0) pat_reset(&s_pat);
 	DigestAcc dacc{0, 0, 0.0};
 	uint32_t flip = 0;
 	const char *bbase = reinterpret_cast<const char *>(m.btup);
@@ -2406,7 +2508,11 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 							o = atomicCAS(&h_key[h[u]], -1, col);
 						}
 						isnew[u] = o == -1;
-						if (MODE != MODE_COUNT) atomicAdd(&h_val[h[u]], av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]));
+						if (MODE != MODE_COUNT) {
+							const double pv = av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
+							atomicAdd(&h_val[h[u]], pv);
+							if (PAT) pat_note(pat, pv);
+						}
 					}
 					newmask[u] = __ballot(isnew[u]);
 					nnew += (uint32_t)__popcll(newmask[u]);
@@ -2422,6 +2528,7 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 					}
 				}
 			}
+			if (PAT) pat_publish(pat, &s_pat);
 			STAMP(3);
 			lds_barrier();                                          // the cell's products are in the table
 			STAMP(4);
@@ -2439,7 +2546,9 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 				colbits = ep.wshift + (wb - wa > 1 ? 32 - __builtin_clz(wb - wa - 1u) : 0);
 			}
 			STAMP(5);
-			hash_emit<T, NT, MODE>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits);
+			const double pthr = PAT ? pat_threshold(&s_pat, tile.end - tile.beg) : -1.0;
+			hash_emit<T, NT, MODE, PAT>(nocc, rowid, seg, ep, sk, h_key, h_val, occ, s_sort, scr32, dacc, s_cnt, colbase, colbits, m, tile.beg, tile.end, pthr);
+			if (PAT) { lds_barrier(); if (tid == 0) pat_reset(&s_pat); }
 			if (tid == 0) s_nocc = 0;
 			STAMP(6);
 			lds_barrier();                                          // table clean, counter reset: next cell may insert
@@ -2988,12 +3097,13 @@ static void launch_hash(spsamd_ctx *c, const Cell *cells, uint32_t ncell, const 
 	static int per_cu = 0;                     // resident workgroups per CU of this instantiation
 	if (!per_cu) {
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash<T, NT, MODE, WINDOWED>, NT, 0) != hipSuccess || nb < 1) nb = 1;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash<T, NT, MODE, WINDOWED, false>, NT, 0) != hipSuccess || nb < 1) nb = 1;
 		per_cu = nb;
 	}
 	unsigned grid = std::min<unsigned>(ncell, (unsigned)(c->num_cu * per_cu));
 	if (grid >= 64) grid &= ~7u;               // multiple of 8: the XCD-aware walk
-	k_hash<T, NT, MODE, WINDOWED><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, xb, m, bwin, nwin1, ep, sk);
+	if (ep.pattern) k_hash<T, NT, MODE, WINDOWED, true><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, xb, m, bwin, nwin1, ep, sk);
+	else k_hash<T, NT, MODE, WINDOWED, false><<<dim3(grid), dim3(NT), 0, c->stream>>>(cells, ncell, xb, m, bwin, nwin1, ep, sk);
 	SPS_LAUNCH_CHECK();
 }
 
@@ -3065,7 +3175,7 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 		static int per_cu2 = 0;
 		if (!per_cu2) {
 			int nb = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash_tiles2<MODE>, TILE2_NT, 0) != hipSuccess || nb < 1) nb = 1;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hash_tiles2<MODE, false>, TILE2_NT, 0) != hipSuccess || nb < 1) nb = 1;
 			per_cu2 = nb;
 		}
 		const unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)(c->num_cu * per_cu2));
@@ -3073,7 +3183,7 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 		SinkParams sk2 = sk;
 		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
 		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
-		k_hash_tiles2<MODE><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
+		k_hash_tiles2<MODE, false><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
 		{
 			std::vector<unsigned long long> h((size_t)grid * 12);
 			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -3086,7 +3196,8 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 			fprintf(stderr, "\n");
 		}
 #else
-		k_hash_tiles2<MODE><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+		if (ep.pattern) k_hash_tiles2<MODE, true><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+		else k_hash_tiles2<MODE, false><<<dim3(grid), dim3(TILE2_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
 #endif
 		SPS_LAUNCH_CHECK();
 	} else
@@ -3154,7 +3265,7 @@ static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0
 		SinkParams sk2 = sk;
 		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
 		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk2);
+		k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk2);
 		{
 			std::vector<unsigned long long> h((size_t)grid * 12);
 			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -3168,11 +3279,13 @@ static void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0
 		}
 		return;
 #endif
-		k_dense<8192, 512, MODE><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		if (ep.pattern) k_dense<8192, 512, MODE, true><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		else k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
 	} else {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu);
 		if (grid >= 64) grid &= ~7u;
-		k_dense<16384, 1024, MODE><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		if (ep.pattern) k_dense<16384, 1024, MODE, true><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		else k_dense<16384, 1024, MODE, false><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
 	}
 	SPS_LAUNCH_CHECK();
 }
@@ -3201,7 +3314,7 @@ static float elapsed(hipEvent_t a, hipEvent_t b)
 
 // Heavy rows: window index of B, per-row window histogram, counting pass of the cell grouping.
 static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
-	uint32_t extra, uint32_t *nseg, bool ordered)
+	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern)
 {
 	hipStream_t st = c->stream;
 	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
@@ -3245,14 +3358,14 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	// Only the first generation has the ascending-k (ordered) variant.
 	// Default (measured, R-MAT scale 20): the hash tiles for the digest sink (42.6 vs 46.8 ms), the bitmap tiles for
 	// the COO sink, whose COUNT launch is then a popcount and whose STORE launch needs no sort (210 vs 225 ms).
-	hv.tiles2 = ordered ? 1 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : (c->tune.tiles_v1 == 3 ? 0 : (hv.coo ? 0 : 2))));
+	hv.tiles2 = ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : (c->tune.tiles_v1 == 3 ? 0 : (hv.coo ? 0 : 2))));
 	hv.tb.by_items = hv.tiles2 != 1 ? 1 : 0;
 	hv.tb.pb = hv.tiles2 != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
 	hv.span_cap = hv.tiles2 == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	hv.tb2.by_items = 1;
 	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
 	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
-	hv.tb2.enabled = hv.tb.enabled && !c->tune.no_wmajor && !ordered && hv.direct_min < hv.dense_min;
+	hv.tb2.enabled = hv.tb.enabled && !c->tune.no_wmajor && !ordered && !pattern && hv.direct_min < hv.dense_min;
 	hv.tb2.pb = (uint32_t)hv.W;      // items of a direct tile: one bit each in a W-bit bitmap
 	for (TileBases *t : {&hv.tb, &hv.tb2}) {
 		t->ntc = c->arena.get<uint32_t>(hv.n); t->ntl = c->arena.get<uint32_t>(hv.n);
@@ -3366,7 +3479,7 @@ static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res,
 #ifdef SPSAMD_ABLATIONS
 		c->tune.dbg,
 #endif
-		0u, B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u, 0};
+		0u, B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u, 0, 0};
 	const bool k64 = ep.ncolbits + 6u > 32u;                        // (column << log2 S | A position) does not fit 32 bits
 	SinkParams sk{};
 	sk.err = c->arena.get<uint32_t>(1);
@@ -3518,7 +3631,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	BTup *btup = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);         // a dense-cell item reads R tuples: slack after the last one
 	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
 	SPS_LAUNCH_CHECK();
-	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, elo, elen};
+	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, btup, elo, elen};
 #ifdef SPSAMD_ABLATIONS
 	SPS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl), &c->tune.dbg, sizeof(int), 0, hipMemcpyHostToDevice, st));
 #endif
@@ -3529,7 +3642,8 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 #endif
 		0u,
 		B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u,
-		(a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0};
+		(a.sink_flags & SPSAMD_SINK_ORDERED) ? 1 : 0,
+		((a.sink_flags & SPSAMD_SINK_EXACT_PATTERN) && !(a.sink_flags & SPSAMD_SINK_ORDERED)) ? 1 : 0};
 
 	// ---- segments (one per light/mid row, one per cell of a heavy row) and the heavy rows' cells
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
@@ -3538,7 +3652,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	Heavy hv;
 	hv.n = bins.count[8];
 	hv.coo = coo;
-	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0);
+	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0, (a.sink_flags & SPSAMD_SINK_EXACT_PATTERN) != 0);
 	ep.wshift = hv.W == 8192 ? 13u : 14u;
 	uint32_t *segbase = nullptr;
 	int64_t nsegs = 0;

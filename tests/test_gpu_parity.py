@@ -610,6 +610,61 @@ def test_ordered_mode_exact_cancellation(ctx):
     assert got[3].nnz == 0 and got[3].products == k * ncol
 
 
+@pytest.mark.parametrize("spread", [1, 64], ids=["dense_cells", "hash_cells"])
+def test_exact_pattern_mode_cancellation(ctx, spread):
+    """SPSAMD_SINK_EXACT_PATTERN: the reference's index set at arrival-order speed.  Terms that cancel to exactly 0
+    only in ascending k (1e16 + 1 - 1e16) must be dropped like the reference drops them (multiply_sparse.hpp:238),
+    terms that cancel only in SOME other order (1e16 - 1e16 + 1 = 1) must be kept with the reference's value -- in the
+    dense-window cells (spread 1: 9000 products in one window) and in the hash cells (spread 64: 24 windows)."""
+    from spsparse_amd import capi
+    k, ncol = 3, 3000
+    cols = np.arange(ncol) * spread
+    A = orc.Mat([0] * k, list(range(k)), [1.0, 1.0, 1.0], (1, k))
+    bi0 = np.repeat(np.arange(k), ncol)
+    bi1 = np.tile(cols, k)
+    for vals, expect in (([1e16, 1.0, -1e16], None), ([1e16, -1e16, 1.0], 1.0)):
+        B = orc.Mat(bi0, bi1, np.repeat(np.array(vals), ncol), (k, ncol * spread))
+        want = orc.multiply(A, B, rowwise=True)
+        assert len(want[2]) == (0 if expect is None else ncol)
+        got = _dev(ctx, A, B, flags=capi.SINK_EXACT_PATTERN)
+        assert got[3].rows_heavy == 1 and got[3].products == k * ncol
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        d = _dev(ctx, A, B, sink=capi.SINK_DIGEST, flags=capi.SINK_EXACT_PATTERN)[3]
+        cnt, ssum, h = orc.digest(*want[:3])
+        assert (d.nnz, d.hash) == (cnt, h) and d.sum == ssum
+
+
+def test_exact_pattern_mode_mixed_signs(ctx):
+    """Mixed-sign values on a matrix with light, hash-cell and dense-cell rows: with EXACT_PATTERN the index set is the
+    oracle's (ascending-k sums); values agree to the rounding of an arrival-order sum (relative to the sum of |terms|),
+    and where the flag re-evaluated a sum it is the oracle's value bit for bit.  Integer-valued operands make exact
+    cancellation common."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(21)
+    a = wl.rmat(15, seed=6)
+    vals = rng.integers(-3, 4, size=a[2].size).astype(np.float64)
+    vals[vals == 0] = 1.0
+    A = orc.Mat(a[0], a[1], vals, a[3])
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    got = _dev(ctx, A, A, flags=capi.SINK_EXACT_PATTERN)
+    assert got[3].cells_dense > 0 and got[3].cells_hash > 0 and got[3].rows_mid > 0
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2])                  # small integers: every order is exact
+    plain = _dev(ctx, A, A)                                  # the default mode has the same pattern here: sums of integers are exact
+    assert np.array_equal(plain[0], want[0])
+    # real-valued mixed signs: pattern identical, values to rounding
+    vals2 = rng.standard_normal(a[2].size)
+    A2 = orc.Mat(a[0], a[1], vals2, a[3])
+    want2 = orc.multiply(A2, A2, rowwise=True, nthreads=8)
+    got2 = _dev(ctx, A2, A2, flags=capi.SINK_EXACT_PATTERN)
+    assert np.array_equal(got2[0], want2[0]) and np.array_equal(got2[1], want2[1])
+    absA = orc.Mat(a[0], a[1], np.abs(vals2), a[3])
+    bound = orc.multiply(absA, absA, rowwise=True, nthreads=8)     # sum of |terms| per output, same pattern superset
+    key = lambda r: r[0].astype(np.int64) * a[3][1] + r[1]
+    pos = np.searchsorted(key(bound), key(want2))
+    assert np.all(np.abs(got2[2] - want2[2]) <= 1e-12 * bound[2][pos])
+
+
 def test_poisson_exact(ctx):
     """cfg3 at N=64: values are small integers, so every summation order is exact;
     closed forms nnz(A)=5N^2-4N, P=25N^2-36N+8, nnz(C)=13N^2-20N+4."""
