@@ -181,7 +181,12 @@ class Workload:
 
 def run_workload(torch, w, steps, warmup):
     """warmup + timed steps of one workload on one GPU; returns the summary dict and the per-step results."""
+    # setup: size the library's workspace so that no timed step allocates device memory -- a first estimate, one
+    # untimed sizing call, then one slab of what that call really used (the window indices of the heavy-row path
+    # grow with rows x windows: 190 B per raw tuple at R-MAT scale 20, 380 B at scale 23)
     w.ctx.reserve(w.workspace)
+    used = max(int(r.workspace_bytes) for r in w.step())
+    w.ctx.reserve(max(w.workspace, int(used * 1.08) + (256 << 20)))
     for _ in range(warmup):
         w.step()
     torch.cuda.synchronize()
@@ -414,11 +419,16 @@ def roofline_of(args, world, results, scale_is_cfg2):
 
     def avg(f):
         return sum(f(r) for r in results) / len(results)
-    p_hash = res.products_heavy - res.products_dense
     t_heavy = max(1, res.products_heavy)
+    p_win = res.products_heavy - res.products_dense - res.products_tiles - res.products_direct     # windowed k_hash (rows with > 256 A tuples)
+
+    def tup(p):                                     # A tuples attributed in proportion to the products
+        return res.tuples_heavy * p / t_heavy
     kernels = [
-        ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, res.tuples_heavy * res.products_dense / t_heavy),
-        ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense), p_hash, res.tuples_heavy * p_hash / t_heavy),
+        ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, tup(res.products_dense)),
+        ("k_hash_tiles", avg(lambda r: r.ms_tiles), res.products_tiles, tup(res.products_tiles)),
+        ("k_direct_tiles", avg(lambda r: r.ms_direct), res.products_direct, tup(res.products_direct)),
+        ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense - r.ms_tiles - r.ms_direct), p_win, tup(p_win)),
         ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
         ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
     ]
@@ -441,7 +451,8 @@ def roofline_of(args, world, results, scale_is_cfg2):
     return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
             "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel,
-            "all_kernels_ms": {k[0]: k[1] for k in kernels}}
+            "all_kernels": {k[0]: {"ms": k[1], "products": int(k[2]),
+                                   "frac": (16 * k[3] + 12 * k[2]) / (k[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS if k[1] > 0 else None} for k in kernels}}
 
 
 def headline(args, world, wname, n, ne, nnz_a, products, nnz_c, vsum, vhash, ms_step, elapsed, results, remote_total, calib, par):

@@ -151,6 +151,10 @@ typedef struct {
 	uint64_t rows_light, rows_mid, rows_heavy;
 	uint64_t products_light, products_mid, products_heavy;
 	uint64_t tuples_light, tuples_mid, tuples_heavy;      /* A tuples in the rows of each class */
+	/* the heavy rows' hash-class cells by kernel: tiles (rows with <= 256 A tuples: hash / bitmap tiles), direct tiles;
+	 * the rest of ms_heavy - ms_dense is the windowed k_hash of the longer rows */
+	float ms_tiles, ms_direct;
+	uint64_t products_tiles, products_direct;
 } spsamd_result;
 
 /* ---- context ---- */

@@ -53,7 +53,8 @@ class Result(C.Structure):
                 ("ms_dense", C.c_float), ("window", C.c_uint32), ("cells_hash", C.c_uint64), ("cells_dense", C.c_uint64), ("products_dense", C.c_uint64), ("workspace_bytes", C.c_uint64),
                 ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
                 ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64),
-                ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64)]
+                ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64),
+                ("ms_tiles", C.c_float), ("ms_direct", C.c_float), ("products_tiles", C.c_uint64), ("products_direct", C.c_uint64)]
 
 
 class DistStats(C.Structure):

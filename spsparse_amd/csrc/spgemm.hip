@@ -1724,7 +1724,7 @@ struct CellLists { Cell *list[NCLS]; };
 struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; int by_items; };
 // Two kinds of tile: [0] hash cells (ranges of sparse windows, LDS hash table), [1] direct cells (ONE window holding
 // more than direct_min products, dense window accumulator with claim-by-exchange emission: k_direct_tiles)
-struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; };    // span_cap: most windows one tile cell may cover (0: any)
+struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; uint32_t long_cap; uint32_t long_dense_min; };   // long_*: cell_cap / dense_min of the rows too long for tiles    // span_cap: most windows one tile cell may cover (0: any)
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
@@ -1739,13 +1739,17 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	proto.beg = rbeg[r]; proto.end = rbeg[r + 1]; proto.rowid = rid[r]; proto.pad[0] = proto.pad[1] = 0;
 	const uint32_t *wp = winprod + (uint64_t)h * nwin;
 	uint32_t n[NCLS] = {};
-	unsigned long long np[NCLS] = {};
+	unsigned long long np[NCLS + 2] = {};                              // + the two tile kinds
 	uint32_t ordinal = 0;
 	uint32_t cur = 0, start = 0, last = 0;
 	// rows with few A tuples: their hash / direct cells are grouped into tiles that share one expansion
 	const uint32_t L = proto.end - proto.beg;
 	const bool tileable = tk.k[0].enabled && L <= TILE_LMAX;
 	const bool direct_ok = tileable && tk.k[1].enabled;
+	// a hash cell of a row with many A tuples visits all of them whatever it holds: such rows get larger cells
+	if (!tileable && tk.long_cap > cell_cap) cell_cap = tk.long_cap;
+	// ... and their windows go to the dense kernel much earlier: walking a long row costs more than scanning the window
+	if (!tileable && tk.long_dense_min && tk.long_dense_min < dense_min) dense_min = tk.long_dense_min;
 	uint32_t lsh = 0;
 	while ((1u << lsh) < L) ++lsh;
 	const uint32_t G = min((uint32_t)TILE_NT >> lsh, TILE_MAXCELLS);
@@ -1771,7 +1775,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 			tk.k[kd].tcells[tk.k[kd].tcbase[h] + ntc[kd]] = tc;
 		}
 		++ntc[kd]; ++tcnt[kd]; tcost[kd] += cost; tprods[kd] += prods;
-		np[0] += prods;                                                  // counted with the hash products
+		np[NCLS + kd] += prods;
 		++ordinal;
 	};
 	auto flush = [&]() {
@@ -1825,7 +1829,8 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	close_tile(1);
 	if (!WRITE) {
 #pragma unroll
-		for (int k = 0; k < NCLS; ++k) { cnt.base[k][h] = n[k]; if (np[k]) atomicAdd(&clsprod[k], np[k]); }
+		for (int k = 0; k < NCLS; ++k) cnt.base[k][h] = n[k];
+		for (int k = 0; k < NCLS + 2; ++k) if (np[k]) atomicAdd(&clsprod[k], np[k]);
 		nseg[r] = ordinal;
 		for (int kd = 0; kd < 2; ++kd) if (tk.k[kd].enabled) { tk.k[kd].ntc[h] = ntc[kd]; tk.k[kd].ntl[h] = ntl[kd]; }
 	}
@@ -3136,8 +3141,9 @@ struct Heavy {
 	uint32_t direct_min = 0;
 	int tiles2 = 0;
 	uint32_t span_cap = 0;
+	uint32_t long_cap = 0, long_dense_min = 0;
 	bool coo = false;                // the tiles also serve a STORE launch
-	unsigned long long clsprod[NCLS] = {};
+	unsigned long long clsprod[NCLS + 2] = {};
 	uint32_t *wptr = nullptr;        // window-major copy of B (dense cells): row pointer per window ...
 	BTup *btw = nullptr;             // ... and tuples
 	uint64_t nrowb = 0;
@@ -3147,6 +3153,7 @@ struct Heavy {
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
+	SPS_HIP(hipEventRecord(c->ev2[0], c->stream));
 	if (hv.ntile && hv.tiles2 == 0) {
 		const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;
 		const unsigned grid = std::min<unsigned>(hv.ntile, (unsigned)c->num_cu * 2u);
@@ -3230,6 +3237,7 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 #endif
 		SPS_LAUNCH_CHECK();
 	}
+	SPS_HIP(hipEventRecord(c->ev2[1], c->stream));
 	if (hv.ntile2) {
 		RowMeta m2 = m;
 		m2.btup = hv.btw;
@@ -3243,6 +3251,7 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 		}
 		SPS_LAUNCH_CHECK();
 	}
+	SPS_HIP(hipEventRecord(c->ev2[2], c->stream));
 	launch_hash<1024, 256, MODE, true>(c, hv.cells[0], hv.ncell[0], hv.xb[0], m, hv.bwin, hv.nwin1, ep, sk);
 	launch_hash<3072, 512, MODE, true>(c, hv.cells[1], hv.ncell[1], hv.xb[1], m, hv.bwin, hv.nwin1, ep, sk);
 	launch_hash<4096, 512, MODE, true>(c, hv.cells[2], hv.ncell[2], hv.xb[2], m, hv.bwin, hv.nwin1, ep, sk);
@@ -3351,8 +3360,8 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	if (c->tune.cell_cap >= 64 && c->tune.cell_cap <= (int)CELL_CAP) hv.cell_cap = (uint32_t)c->tune.cell_cap;
 	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
 	// (a window between dense_min and cell_cap products becomes a dense cell; smaller ones are grouped up to cell_cap)
-	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS);
-	fill_zero(c, clsprod, NCLS * sizeof(unsigned long long));
+	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
+	fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
 	hv.tb.enabled = !c->tune.no_tiles;
 	// tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles, second generation.
 	// Only the first generation has the ascending-k (ordered) variant.
@@ -3361,6 +3370,8 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	hv.tiles2 = ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : (c->tune.tiles_v1 == 3 ? 0 : (hv.coo ? 0 : 2))));
 	hv.tb.by_items = hv.tiles2 != 1 ? 1 : 0;
 	hv.tb.pb = hv.tiles2 != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : 0u;
+	hv.long_cap = c->tune.long_cap > 0 ? (uint32_t)std::min<int>(c->tune.long_cap, (int)CELL_CAP) : 0u;
 	hv.span_cap = hv.tiles2 == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	hv.tb2.by_items = 1;
 	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
@@ -3372,7 +3383,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
 		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
 	}
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap});
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min});
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
@@ -3384,7 +3395,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	hv.ntile = read_back(c, hv.tb.tlbase + hv.n);
 	hv.ntcell2 = read_back(c, hv.tb2.tcbase + hv.n);
 	hv.ntile2 = read_back(c, hv.tb2.tlbase + hv.n);
-	for (int k = 0; k < NCLS; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
+	for (int k = 0; k < NCLS + 2; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
 	if ((hv.ncell[CLS_DENSE] || hv.ntile2) && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
 }
 
@@ -3400,7 +3411,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
 	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
 	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap});
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min});
 	SPS_LAUNCH_CHECK();
 	for (int kd = 0; kd < 2; ++kd) {
 		TileBases &t = kd ? hv.tb2 : hv.tb;
@@ -3677,6 +3688,8 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->cells_dense = hv.ncell[CLS_DENSE];
 	res->window = hv.n ? (uint32_t)hv.W : 0u;
 	res->products_dense = hv.clsprod[CLS_DENSE];
+	res->products_tiles = hv.clsprod[NCLS];
+	res->products_direct = hv.clsprod[NCLS + 1];
 	SPS_HIP(hipEventRecord(c->ev[2], st));
 
 	// ---- numeric
@@ -3776,6 +3789,7 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->ms_symbolic = elapsed(c->ev[1], c->ev[2]);
 	res->ms_numeric = elapsed(c->ev[2], c->ev[7]);
 	res->ms_light = ms_light; res->ms_mid = ms_mid; res->ms_heavy = ms_heavy; res->ms_dense = ms_dense;
+	if (hv.n) { res->ms_tiles = elapsed(c->ev2[0], c->ev2[1]); res->ms_direct = elapsed(c->ev2[1], c->ev2[2]); }    // (COO: of the STORE launches)
 }
 
 } // namespace spsamd
