@@ -1724,7 +1724,7 @@ struct CellLists { Cell *list[NCLS]; };
 struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; int by_items; };
 // Two kinds of tile: [0] hash cells (ranges of sparse windows, LDS hash table), [1] direct cells (ONE window holding
 // more than direct_min products, dense window accumulator with claim-by-exchange emission: k_direct_tiles)
-struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; uint32_t long_cap; uint32_t long_dense_min; };   // long_*: cell_cap / dense_min of the rows too long for tiles    // span_cap: most windows one tile cell may cover (0: any)
+struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; uint32_t long_cap; uint32_t long_dense_min; uint32_t tile_cap; };   // long_*: cell_cap / dense_min of the rows too long for tiles    // span_cap: most windows one tile cell may cover (0: any)
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
@@ -1747,6 +1747,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	const bool tileable = tk.k[0].enabled && L <= TILE_LMAX;
 	const bool direct_ok = tileable && tk.k[1].enabled;
 	// a hash cell of a row with many A tuples visits all of them whatever it holds: such rows get larger cells
+	if (tileable && tk.tile_cap > cell_cap) cell_cap = tk.tile_cap;      // tile cells may be larger than a hash table's (bitmap tiles)
 	if (!tileable && tk.long_cap > cell_cap) cell_cap = tk.long_cap;
 	// ... and their windows go to the dense kernel much earlier: walking a long row costs more than scanning the window
 	if (!tileable && tk.long_dense_min && tk.long_dense_min < dense_min) dense_min = tk.long_dense_min;
@@ -1780,7 +1781,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 	};
 	auto flush = [&]() {
 		if (!cur) return;
-		if (tileable && cur <= (uint32_t)(TILE_T / 2)) {
+		if (tileable && cur <= tk.tile_cap) {
 			tile_cell(0, start, last + 1, cur);
 			cur = 0;
 			return;
@@ -2574,10 +2575,18 @@ __global__ __launch_bounds__(TILE2_NT, 4) void k_hash_tiles2(const Tile *tiles, 
 //   3. every product adds its value to acc[rank] (ds_add_f64) and notes its column in colof[rank];
 //   4. acc[0 .. distinct) IS the cell's output in ascending column order: emitted and zeroed, bitmap words cleared.
 // No probing, no compare-and-swap chains, no list of occupied slots, no sort for the COO order; the structural count of
-// a cell (COUNT launch) is just the popcount total.  LDS: bitmap 16 KB + prefix 4 KB + acc 16 KB + colof 8 KB.
+// a cell (COUNT launch) is just the popcount total.  LDS: bitmap 16 KB + prefix 4 KB + acc 32 KB + columns 16 KB: with no
+// table of keys a cell may hold 4096 products instead of a hash table's 2048 -- and per-cell bookkeeping is what sets the
+// tiles' time (42.9 -> 41.8 ms on cfg2 from the cell size alone).
 constexpr int BM_NT = 512;
-constexpr int BM_WORDS = 2048;           // bitmap words: 131072 columns = 16 windows of 8192 (8 of 16384)
-constexpr int BM_MAXOUT = 2048;          // distinct columns of a cell (<= its products <= TILE_T / 2)
+#ifndef BM_WORDS_V
+#define BM_WORDS_V 2048
+#endif
+constexpr int BM_WORDS = BM_WORDS_V;      // bitmap words: 2048 = 131072 columns = 16 windows of 8192 (8 of 16384)
+#ifndef BM_MAXOUT_V
+#define BM_MAXOUT_V 4096
+#endif
+constexpr int BM_MAXOUT = BM_MAXOUT_V;   // distinct columns of a cell (<= its products)
 constexpr int BM_ITEMS = 8192;           // items per tile
 
 template <int MODE>
@@ -2586,12 +2595,12 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 {
 	constexpr int NT = BM_NT, NW = NT / 64, R = DENSE_R;
 	constexpr int NWORD = BM_ITEMS / 64;
-	constexpr int MAXST = 3;
+	constexpr int MAXST = (BM_MAXOUT / R + (int)TILE_LMAX + 64 + NT - 1) / NT;      // 64-item blocks of one cell per wave
 	constexpr int WPT = BM_WORDS / NT;       // bitmap words per thread in the scan (4)
 	__shared__ unsigned long long bm[BM_WORDS];
 	__shared__ uint16_t bpre[BM_WORDS];
 	__shared__ double acc[BM_MAXOUT];
-	__shared__ uint32_t colof[BM_MAXOUT];
+	__shared__ uint32_t colof[BM_MAXOUT];                       // column (relative to the cell's first) of every rank
 	__shared__ TileX<NT, NWORD> X;
 	__shared__ uint32_t s_wtot[2][NW];
 	__shared__ uint32_t s_scan[NW + 1];
@@ -2752,26 +2761,30 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 				continue;
 			}
 			STAMP(4);
-			lds_barrier();                                          // prefix visible
-			STAMP(5);
-			// ---- 3. accumulate by rank
+			// ---- 3. accumulate by rank (the structural count needs no values: it walks the words directly)
+			if constexpr (MODE != MODE_COUNT) {
+				lds_barrier();                                      // prefix visible
+				STAMP(5);
 #pragma unroll
-			for (int st = 0; st < MAXST; ++st) {
+				for (int st = 0; st < MAXST; ++st) {
 #pragma unroll
-				for (int u = 0; u < R; ++u) {
-					const uint32_t rel = krel[st][u];
-					if (rel != 0xFFFFFFFFu) {
-						const uint32_t w = rel >> 6;
-						const uint32_t rank = (uint32_t)bpre[w] + (uint32_t)__popcll(bm[w] & ((1ull << (rel & 63u)) - 1ull));
-						if constexpr (MODE != MODE_COUNT) atomicAdd(&acc[rank], kval[st][u]);
-						colof[rank] = rel;
+					for (int u = 0; u < R; ++u) {
+						const uint32_t rel = krel[st][u];
+						if (rel != 0xFFFFFFFFu) {
+							const uint32_t w = rel >> 6;
+							const uint32_t rank = (uint32_t)bpre[w] + (uint32_t)__popcll(bm[w] & ((1ull << (rel & 63u)) - 1ull));
+							atomicAdd(&acc[rank], kval[st][u]);
+							colof[rank] = rel;
+						}
 					}
 				}
+				STAMP(6);
+				lds_barrier();                                      // acc[0 .. distinct) holds the cell's sums in column order
+				STAMP(7);
 			}
-			STAMP(6);
-			lds_barrier();                                          // acc[0 .. distinct) holds the cell's sums in column order
-			STAMP(7);
-			// ---- 4. emit in order, clean the accumulator and the bitmap words that were used
+			// ---- 4. emit in order: thread i takes rank i (perfectly balanced -- walking the set bits of the words instead
+			// leaves the barrier waiting for the thread with the fullest word: 94 vs 42 ms), cleans the accumulator entry
+			// and the bitmap word of its column
 			if constexpr (MODE == MODE_DIGEST) {
 				unsigned long long cnt = 0; double vs = 0;
 				for (uint32_t i = tid; i < distinct; i += NT) {
@@ -2789,19 +2802,33 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
 				}
 			} else if constexpr (MODE == MODE_COUNT) {
-				// scalek present: count the allowed columns
+				// scalek present: count the allowed columns (every thread walks its own words: no values were accumulated)
 				uint32_t cnt = 0;
-				for (uint32_t i = tid; i < distinct; i += NT) {
-					const uint32_t rel = colof[i];
-					bm[rel >> 6] = 0ull;
-					if (col_allowed(ep, (int32_t)(colbase + rel))) ++cnt;
+#pragma unroll
+				for (int x = 0; x < WPT; ++x) {
+					if (!wcnt[x]) continue;
+					const uint32_t w = tid * WPT + x;
+					unsigned long long word = bm[w];
+					bm[w] = 0ull;
+					while (word) {
+						const uint32_t bit = (uint32_t)__builtin_ctzll(word);
+						word &= word - 1ull;
+						if (col_allowed(ep, (int32_t)(colbase + (w << 6) + bit))) ++cnt;
+					}
 				}
 				uint32_t tot;
 				block_exclusive_scan<uint32_t, NT>(cnt, s_scan, &tot);
 				if (tid == 0) sk.segcount[seg] = tot;
 			} else {
-				// COO: rank order IS column order; sums that cancelled to exactly 0 (or columns scalek drops) leave no
-				// tuple, so the survivors are compacted with one more scan
+				// COO: rank order IS column order.  Usually every column of the cell yields a tuple and its place is its
+				// rank; only where a sum cancelled to exactly 0 (or scalek drops a column) the survivors are compacted by scans
+				uint32_t nbad = 0;
+				for (uint32_t i = tid; i < distinct; i += NT) {
+					double v = acc[i];
+					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + colof[i]), v, &v);
+					if (!ok) ++nbad;
+				}
+				const int any_bad = __syncthreads_or((int)nbad);
 				const int64_t o = sk.segoff[seg];
 				uint32_t run = 0;
 				for (uint32_t ibase = 0; ibase < distinct; ibase += NT) {
@@ -2814,16 +2841,16 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 						bm[rel >> 6] = 0ull;
 						ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v);
 					}
-					uint32_t tot;
-					const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);
-					if (ok) {
-						sk.out_i[o + run + ex] = rowid;
-						sk.out_j[o + run + ex] = (int32_t)(colbase + rel);
-						sk.out_v[o + run + ex] = v;
+					uint32_t at = i;
+					if (any_bad) {                                          // uniform
+						uint32_t tot;
+						const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);
+						at = run + ex;
+						run += tot;
 					}
-					run += tot;
+					if (ok) { sk.out_i[o + at] = rowid; sk.out_j[o + at] = (int32_t)(colbase + rel); sk.out_v[o + at] = v; }
 				}
-				if (tid == 0) sk.segactual[seg] = run;
+				if (tid == 0) sk.segactual[seg] = any_bad ? run : distinct;
 			}
 			STAMP(8);
 			lds_barrier();                                          // clean: the next cell may set bits
@@ -3365,9 +3392,10 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	hv.tb.enabled = !c->tune.no_tiles;
 	// tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles, second generation.
 	// Only the first generation has the ascending-k (ordered) variant.
-	// Default (measured, R-MAT scale 20): the hash tiles for the digest sink (42.6 vs 46.8 ms), the bitmap tiles for
-	// the COO sink, whose COUNT launch is then a popcount and whose STORE launch needs no sort (210 vs 225 ms).
-	hv.tiles2 = ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : (c->tune.tiles_v1 == 3 ? 0 : (hv.coo ? 0 : 2))));
+	// Default: the bitmap-rank tiles for both sinks (measured, R-MAT scale 20: digest 42.0 vs 42.8 ms for the hash tiles
+	// v2 and 44.5 for the first generation; COO 196 vs 225 ms -- the COUNT launch is a popcount, the STORE launch needs
+	// no sort).  EXACT_PATTERN runs on the hash tiles v2, ORDERED on the first generation (the variants that exist).
+	hv.tiles2 = ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : 0));
 	hv.tb.by_items = hv.tiles2 != 1 ? 1 : 0;
 	hv.tb.pb = hv.tiles2 != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
 	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : 0u;
@@ -3383,7 +3411,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
 		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
 	}
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min});
+	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min, hv.tiles2 == 0 ? (uint32_t)BM_MAXOUT : (uint32_t)(TILE_T / 2)});
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
@@ -3411,7 +3439,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
 	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
 	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min});
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min, hv.tiles2 == 0 ? (uint32_t)BM_MAXOUT : (uint32_t)(TILE_T / 2)});
 	SPS_LAUNCH_CHECK();
 	for (int kd = 0; kd < 2; ++kd) {
 		TileBases &t = kd ? hv.tb2 : hv.tb;
