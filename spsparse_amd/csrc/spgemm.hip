@@ -1724,7 +1724,8 @@ struct CellLists { Cell *list[NCLS]; };
 struct TileBases { uint32_t *ntc, *ntl, *tcbase, *tlbase; TCell *tcells; Tile *tiles; int enabled; uint32_t pb; int by_items; };
 // Two kinds of tile: [0] hash cells (ranges of sparse windows, LDS hash table), [1] direct cells (ONE window holding
 // more than direct_min products, dense window accumulator with claim-by-exchange emission: k_direct_tiles)
-struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; uint32_t long_cap; uint32_t long_dense_min; uint32_t tile_cap; };   // long_*: cell_cap / dense_min of the rows too long for tiles    // span_cap: most windows one tile cell may cover (0: any)
+struct TileKinds { TileBases k[2]; uint32_t direct_min; uint32_t span_cap; uint32_t long_cap; uint32_t long_dense_min; uint32_t tile_cap;
+	uint32_t alt_cap, alt_span; unsigned long long *alt_cells; };   // alt_*: (counting pass) the tile cells another cap / span would give   // long_*: cell_cap / dense_min of the rows too long for tiles    // span_cap: most windows one tile cell may cover (0: any)
 
 template <bool WRITE>
 __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
@@ -1793,6 +1794,9 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		}
 		++n[cls]; np[cls] += cur; ++ordinal; cur = 0;
 	};
+	// the alternative tile scheme's cell count (counting pass only): same greedy grouping with its own cap and span
+	uint32_t alt_cur = 0, alt_start = 0, alt_n = 0;
+	const bool alt_on = !WRITE && tk.alt_cells && tileable;
 	// the row's histogram is read four windows per load where the row is 16-byte aligned (one thread per
 	// row: consecutive threads are a whole row apart, so narrow loads waste most of every cache line)
 	const bool vec4 = (nwin & 3u) == 0;
@@ -1803,6 +1807,14 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 			if ((w & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(wp + w);
 			c = (w & 3u) == 0 ? quad.x : ((w & 3u) == 1 ? quad.y : ((w & 3u) == 2 ? quad.z : quad.w));
 		} else c = wp[w];
+		if (alt_on) {
+			if (c > dense_min || (direct_ok && c > tk.direct_min)) { if (alt_cur) { ++alt_n; alt_cur = 0; } }
+			else if (c > 0) {
+				if (alt_cur && (alt_cur + c > tk.alt_cap || (tk.alt_span && w - alt_start >= tk.alt_span))) { ++alt_n; alt_cur = 0; }
+				if (!alt_cur) alt_start = w;
+				alt_cur += c;
+			}
+		}
 		if (c > dense_min) {
 			flush();
 			if (WRITE) {
@@ -1834,6 +1846,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		for (int k = 0; k < NCLS + 2; ++k) if (np[k]) atomicAdd(&clsprod[k], np[k]);
 		nseg[r] = ordinal;
 		for (int kd = 0; kd < 2; ++kd) if (tk.k[kd].enabled) { tk.k[kd].ntc[h] = ntc[kd]; tk.k[kd].ntl[h] = ntl[kd]; }
+		if (alt_on) { if (alt_cur) ++alt_n; if (alt_n) atomicAdd(tk.alt_cells, (unsigned long long)alt_n); }
 	}
 }
 
@@ -3168,6 +3181,8 @@ struct Heavy {
 	uint32_t direct_min = 0;
 	int tiles2 = 0;
 	uint32_t span_cap = 0;
+	uint32_t alt_cap = 0, alt_span = 0;
+	unsigned long long *alt_cells = nullptr;
 	uint32_t long_cap = 0, long_dense_min = 0;
 	bool coo = false;                // the tiles also serve a STORE launch
 	unsigned long long clsprod[NCLS + 2] = {};
@@ -3176,6 +3191,13 @@ struct Heavy {
 	uint64_t nrowb = 0;
 	uint32_t nnzb = 0;
 };
+
+static TileKinds tile_kinds(const Heavy &hv)
+{
+	TileKinds tk{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min,
+		hv.tiles2 == 0 ? (uint32_t)BM_MAXOUT : (uint32_t)(TILE_T / 2), hv.alt_cap, hv.alt_span, hv.alt_cells};
+	return tk;
+}
 
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
@@ -3390,17 +3412,19 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
 	fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
 	hv.tb.enabled = !c->tune.no_tiles;
-	// tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles, second generation.
-	// Only the first generation has the ascending-k (ordered) variant.
-	// Default: the bitmap-rank tiles for both sinks (measured, R-MAT scale 20: digest 42.0 vs 42.8 ms for the hash tiles
-	// v2 and 44.5 for the first generation; COO 196 vs 225 ms -- the COUNT launch is a popcount, the STORE launch needs
-	// no sort).  EXACT_PATTERN runs on the hash tiles v2, ORDERED on the first generation (the variants that exist).
-	hv.tiles2 = ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : 0));
-	hv.tb.by_items = hv.tiles2 != 1 ? 1 : 0;
-	hv.tb.pb = hv.tiles2 != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+	// Tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles v2.
+	// ORDERED runs on the first generation, EXACT_PATTERN on the hash tiles v2 (the variants that exist); otherwise the
+	// choice is made per call below, by counting the cells either scheme would cut.
+	const bool free_choice = !ordered && !pattern && c->tune.tiles_v1 == 0;
+	auto set_scheme = [&](int scheme) {
+		hv.tiles2 = scheme;
+		hv.tb.by_items = scheme != 1 ? 1 : 0;
+		hv.tb.pb = scheme != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+		hv.span_cap = scheme == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
+	};
+	set_scheme(ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : 0)));
 	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : 0u;
 	hv.long_cap = c->tune.long_cap > 0 ? (uint32_t)std::min<int>(c->tune.long_cap, (int)CELL_CAP) : 0u;
-	hv.span_cap = hv.tiles2 == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	hv.tb2.by_items = 1;
 	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
 	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
@@ -3411,8 +3435,31 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
 		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
 	}
-	k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min, hv.tiles2 == 0 ? (uint32_t)BM_MAXOUT : (uint32_t)(TILE_T / 2)});
-	SPS_LAUNCH_CHECK();
+	auto count_pass = [&]() {
+		fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
+		for (TileBases *t : {&hv.tb, &hv.tb2}) { fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t)); }
+		k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, tile_kinds(hv));
+		SPS_LAUNCH_CHECK();
+	};
+	if (free_choice && hv.tb.enabled) {
+		// Bitmap tiles hold 4096 products per cell but at most 16 windows of columns; hash tiles 2048 products over any
+		// range.  Per-cell bookkeeping is what the tile kernels' time is, so the scheme that cuts clearly fewer cells wins
+		// (break-even measured near 1.15 hash cells per bitmap cell): R-MAT scale 20 takes the bitmap tiles (3.22 M against
+		// 3.85 M cells: 42.0 vs 42.8 ms), scale 23 -- sparse rows spread over 512 windows, 150 M against 65 M cells -- the
+		// hash tiles (0.96 vs 1.35 s).  The counting pass of the bitmap scheme also counts the cells the hash scheme would
+		// cut; only where that one wins is the pass repeated.
+		set_scheme(0);
+		hv.alt_cap = (uint32_t)(TILE_T / 2); hv.alt_span = 0;
+		hv.alt_cells = c->arena.get<unsigned long long>(1);
+		fill_zero(c, hv.alt_cells, sizeof(unsigned long long));
+		count_pass();
+		scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
+		const uint32_t cells_bm = read_back(c, hv.tb.tcbase + hv.n);
+		const unsigned long long cells_hash = read_back(c, hv.alt_cells);
+		hv.alt_cells = nullptr;
+		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %u hash %llu\n", cells_bm, cells_hash);
+		if ((uint64_t)cells_bm * 115u > (uint64_t)cells_hash * 100u) { set_scheme(2); count_pass(); }
+	} else count_pass();
 	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
 	scan_exclusive_u32_u32(c, hv.tb.ntl, hv.tb.tlbase, hv.n);
@@ -3439,7 +3486,7 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
 	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
 	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
-	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, TileKinds{{hv.tb, hv.tb2}, hv.direct_min, hv.span_cap, hv.long_cap, hv.long_dense_min, hv.tiles2 == 0 ? (uint32_t)BM_MAXOUT : (uint32_t)(TILE_T / 2)});
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, tile_kinds(hv));
 	SPS_LAUNCH_CHECK();
 	for (int kd = 0; kd < 2; ++kd) {
 		TileBases &t = kd ? hv.tb2 : hv.tb;
