@@ -136,7 +136,7 @@ static unsigned grid_for(size_t n, unsigned bs = 256) { return (unsigned)((n + b
 template <class T>
 static const T *to_device(spsamd_ctx *c, const T *p, size_t n, int mem)
 {
-	if (mem == SPSAMD_MEM_DEVICE || n == 0) return p;
+	if (mem != SPSAMD_MEM_HOST || n == 0) return p;
 	T *d = c->arena.get<T>(n);
 	SPS_HIP(hipMemcpyAsync(d, p, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
 	return d;
@@ -158,6 +158,13 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	if (shape[0] > (uint64_t(1) << 31) || shape[1] > (uint64_t(1) << 31))
 		throw Error{SPSAMD_EINVAL, "shape exceeds the int32 index range"};
 
+	if (X->mem == SPSAMD_MEM_DEVICE_VERIFIED && X->sort0 == lead) {       // the distributed step's own block / panel
+		out->row = const_cast<int32_t *>(lead == 0 ? X->idx0 : X->idx1);
+		out->col = const_cast<int32_t *>(lead == 0 ? X->idx1 : X->idx0);
+		out->val = const_cast<double *>(X->val);
+		out->nnz = (uint32_t)n;
+		return;
+	}
 	const int32_t *d0 = to_device(c, X->idx0, n, X->mem);
 	const int32_t *d1 = to_device(c, X->idx1, n, X->mem);
 	const double *dv = to_device(c, X->val, n, X->mem);

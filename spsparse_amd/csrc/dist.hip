@@ -114,6 +114,11 @@ __global__ void k_pack_rows(const int32_t *brow, const int32_t *bcol, const doub
 	pval[dst] = bval[e];
 }
 
+__global__ void k_pick_u32(const uint32_t *src, const uint64_t *at, int n, uint32_t *dst)
+{
+	for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[at[i]];
+}
+
 // panel row index of every tuple from the panel's row pointer (the row array is never sent)
 __global__ void k_expand_rows(const uint32_t *ptr, uint32_t nrow, uint32_t nnz, int32_t *row)
 {
@@ -268,7 +273,14 @@ extern "C" int spsamd_dist_multiply(spsamd_dist *d, double C, const spsamd_coo *
 			scan_exclusive_u32_u32(c, rowlen + (size_t)my_n * p, off + ((size_t)my_n + 1) * p, my_n);
 		}
 		std::vector<uint32_t> send_tuples(W);
-		for (int p = 0; p < W; ++p) send_tuples[p] = read_back(c, off + ((size_t)my_n + 1) * p + my_n);
+		{
+			// the W totals sit one prefix array apart: one strided copy, one synchronisation
+			uint32_t *h = (uint32_t *)c->host_staging((size_t)W * sizeof(uint32_t));
+			SPS_HIP(hipMemcpy2DAsync(h, sizeof(uint32_t), off + my_n, ((size_t)my_n + 1) * sizeof(uint32_t), sizeof(uint32_t), (size_t)W,
+				hipMemcpyDeviceToHost, st));
+			SPS_HIP(hipStreamSynchronize(st));
+			for (int p = 0; p < W; ++p) send_tuples[p] = h[p];
+		}
 		// exchange B: the masked row lengths -> the panel's row lengths over the whole inner dimension
 		uint32_t *plen = c->arena.get<uint32_t>(n_inner + 1);
 		for (int p = 0; p < W; ++p) {
@@ -279,7 +291,17 @@ extern "C" int spsamd_dist_multiply(spsamd_dist *d, double C, const spsamd_coo *
 		uint32_t *pptr = c->arena.get<uint32_t>(n_inner + 1);
 		scan_exclusive_u32_u32(c, plen, pptr, n_inner);
 		std::vector<uint32_t> recv_at(W + 1);
-		for (int p = 0; p <= W; ++p) recv_at[p] = read_back(c, pptr + b_bounds[p]);
+		{
+			uint32_t *picked = c->arena.get<uint32_t>((size_t)W + 1);
+			uint64_t *at = c->arena.get<uint64_t>((size_t)W + 1);
+			SPS_HIP(hipMemcpyAsync(at, b_bounds, ((size_t)W + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+			k_pick_u32<<<dim3(1), dim3(64), 0, st>>>(pptr, at, W + 1, picked);
+			SPS_LAUNCH_CHECK();
+			uint32_t *h = (uint32_t *)c->host_staging(((size_t)W + 1) * sizeof(uint32_t));
+			SPS_HIP(hipMemcpyAsync(h, picked, ((size_t)W + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+			SPS_HIP(hipStreamSynchronize(st));
+			for (int p = 0; p <= W; ++p) recv_at[p] = h[p];
+		}
 		const uint32_t pn = recv_at[W];                                  // tuples of the panel
 		int32_t *prow = c->arena.get<int32_t>(pn ? pn : 1), *pcol = c->arena.get<int32_t>(pn ? pn : 1);
 		double *pval = c->arena.get<double>(pn ? pn : 1);
@@ -312,9 +334,9 @@ extern "C" int spsamd_dist_multiply(spsamd_dist *d, double C, const spsamd_coo *
 		// ---- 4. the block product: both operands consolidated, trusted as they are (sort0 = 0)
 		spsamd_coo Ad, Bd;
 		Ad.idx0 = Ac.row; Ad.idx1 = Ac.col; Ad.val = Ac.val; Ad.nnz = Ac.nnz; Ad.shape0 = A_block->shape0; Ad.shape1 = A_block->shape1;
-		Ad.sort0 = 0; Ad.mem = SPSAMD_MEM_DEVICE;
+		Ad.sort0 = 0; Ad.mem = SPSAMD_MEM_DEVICE_VERIFIED;
 		Bd.idx0 = prow; Bd.idx1 = pcol; Bd.val = pval; Bd.nnz = pn; Bd.shape0 = Bsrc->shape0; Bd.shape1 = Bsrc->shape1;
-		Bd.sort0 = 0; Bd.mem = SPSAMD_MEM_DEVICE;
+		Bd.sort0 = 0; Bd.mem = SPSAMD_MEM_DEVICE_VERIFIED;
 		if (stats) {
 			std::memset(stats, 0, sizeof(*stats));
 			stats->panel_tuples = pn;

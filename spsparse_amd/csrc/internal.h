@@ -134,6 +134,10 @@ T read_back(spsamd_ctx *c, const T *dev)
 	return *h;
 }
 
+// Internal value of spsamd_coo::mem (never part of the public ABI): device arrays this library produced itself and
+// knows to be consolidated with valid indices -- consolidate_operand takes them as they are, without the inspection pass.
+#define SPSAMD_MEM_DEVICE_VERIFIED 3
+
 // ---------------------------------------------------------------- consolidated operand (consolidate.hip)
 
 // op(X) in row-major consolidated form on the device.

@@ -240,8 +240,19 @@ static void test_ordered_flag()
 	}
 	multiply_flags = SPSAMD_SINK_ORDERED;
 	multiply(C, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
-	multiply_flags = 0;
+	multiply_flags = SPSAMD_SINK_EXACT_PATTERN;
 	CHECK(C.size() == 0 && C.shape[0] == 1 && C.shape[1] == (size_t)ncol);
+	// the template's DEFAULT (SPSAMD_SINK_EXACT_PATTERN) drops them too: the index set is the reference's ...
+	Mat D;
+	multiply(D, 1.0, (Vec *)0, A, '.', (Vec *)0, B, '.', (Vec *)0);
+	CHECK(D.size() == 0);
+	// ... and keeps what only another order would cancel: 1e16 - 1e16 + 1 == 1 in ascending k
+	Mat B2({3, (size_t)ncol}), F;
+	const double bv2[3] = {1e16, -1e16, 1.0};
+	for (int k = 0; k < 3; ++k) for (int j = 0; j < ncol; ++j) B2.add({k, j}, bv2[k]);
+	multiply(F, 1.0, (Vec *)0, A, '.', (Vec *)0, B2, '.', (Vec *)0);
+	CHECK(F.size() == (size_t)ncol);
+	for (size_t q = 0; q < F.size(); ++q) CHECK(F.val(q) == 1.0 && F.index(1, q) == (int)q);
 }
 
 int main(int argc, char **argv)
