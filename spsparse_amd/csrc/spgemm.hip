@@ -533,7 +533,14 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 
 	const unsigned w = wave_id(), lane = lane_id();
 	const unsigned g = lane / S, s = lane % S;
+	// Element i of an array: in the narrow variant (every operand array below 4 GB, columns below 2^26) the byte offset is
+	// 32-bit arithmetic on top of a scalar base -- the 64-bit address computations were 50 of the kernel's 176 vector
+	// instructions
+	auto at32 = [](const uint32_t *p, uint32_t i) -> uint32_t { if (K64) return p[i]; return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p) + (uint32_t)(i << 2)); };
+	auto ati32 = [](const int32_t *p, uint32_t i) -> int32_t { if (K64) return p[i]; return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(p) + (uint32_t)(i << 2)); };
+	auto atf64 = [](const double *p, uint32_t i) -> double { if (K64) return p[i]; return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + (uint32_t)(i << 3)); };
 	unsigned long long d_cnt = 0, d_hash = 0, n_prod = 0; double d_sum = 0.0;
+	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;
 	const uint32_t nvb = (nrow + 4u * G - 1u) / (4u * G);
 	// Software pipeline over the row groups of this workgroup: the chain row pointer -> A tuple -> B row bounds ->
 	// B tuples is four dependent global loads; its first three links are fetched one link per round ahead
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		const uint32_t r_ = row_of(vb_);
 		const bool ok = vb_ < nvb && r_ < nrow;
 		const uint32_t rc = ok ? r_ : 0u;
-		b_ = aptr[rc]; e_ = aptr[rc + 1];
+		b_ = at32(aptr, rc); e_ = at32(aptr, rc + 1);
 		if (ep.si_pos) {                                             // scalei: absent or zero -> the row is skipped
 			const int32_t q = ep.si_pos[rc];
 			if (q < 0 || ep.si_val[q] == 0) e_ = b_;
@@ -555,10 +562,10 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		const uint32_t e = b_ + s;
 		v_ = e < e_;
 		const uint32_t ec = v_ ? e : (b_ < e_ ? b_ : 0u);                // any valid tuple (A has at least one)
-		k_ = acol[ec]; a_ = aval[ec];
+		k_ = ati32(acol, ec); a_ = atf64(aval, ec);
 	};
 	auto load_brow = [&](int32_t k_, bool v_, uint32_t &lo_, uint32_t &len_) {
-		const uint32_t l0 = bptr[k_], l1 = bptr[k_ + 1];
+		const uint32_t l0 = at32(bptr, (uint32_t)k_), l1 = at32(bptr, (uint32_t)k_ + 1u);
 		lo_ = l0; len_ = v_ ? l1 - l0 : 0u;
 	};
 	uint32_t beg1, end1, beg2, end2;                                // bounds of round +1, +2
@@ -610,8 +617,8 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		double prod = 0.0;
 		if (act) {
 			const uint32_t bp = slo + (s - sex);
-			const int32_t col = bcol[bp];
-			prod = sa * bval[bp];
+			const int32_t col = ati32(bcol, bp);
+			prod = sa * atf64(bval, bp);
 			key = (key_t)(((key_t)(uint32_t)col << LOGS) | (key_t)(mk - 1u));
 		}
 		s_key[w][lane] = key;
@@ -644,7 +651,9 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		// ---- emit
 		const int32_t rowid = (int32_t)r;
 		double value = 0;
-		const bool out = head && emit_value(ep, row_scale(ep, rowid), (int32_t)mycol, sum, &value);
+		bool out;
+		if (plain) { value = sum; out = head && sum != 0; }          // sum * 1 * 1 * 1 is the same bits (multiply_sparse.hpp:242)
+		else out = head && emit_value(ep, row_scale(ep, rowid), (int32_t)mycol, sum, &value);
 		const uint64_t bal = __ballot(out);
 		const uint64_t gmask = S == 64 ? bal : ((bal >> (g * S)) & ((1ull << (S & 63)) - 1ull));
 		if (s == 0) n_prod += P;
@@ -3566,7 +3575,8 @@ static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res,
 		c->tune.dbg,
 #endif
 		0u, B.ncol > 1 ? (uint32_t)(64 - __builtin_clzll((unsigned long long)(B.ncol - 1))) : 1u, 0, 0};
-	const bool k64 = ep.ncolbits + 6u > 32u;                        // (column << log2 S | A position) does not fit 32 bits
+	// wide variant: (column << log2 S | A position) does not fit 32 bits, or an operand array reaches 4 GB
+	const bool k64 = ep.ncolbits + 6u > 32u || A.nnz >= (1u << 29) || B.nnz >= (1u << 29) || A.nrow + 2 >= (uint64_t(1) << 30) || B.nrow + 3 >= (uint64_t(1) << 30);
 	SinkParams sk{};
 	sk.err = c->arena.get<uint32_t>(1);
 	fill_zero(c, sk.err, sizeof(uint32_t));
