@@ -2625,6 +2625,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 	__shared__ uint32_t colof[BM_MAXOUT];                       // column (relative to the cell's first) of every rank
 	__shared__ TileX<NT, NWORD> X;
 	__shared__ uint32_t s_wtot[2][NW];
+	__shared__ uint32_t s_wbase[NW];
 	__shared__ uint32_t s_scan[NW + 1];
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
@@ -2704,6 +2705,18 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 		uint32_t pbp, pnv; double pav;
 		tile_lookup(X, tab, nzc, (X.cellI[0] >> 6) + wv, X.cellI[1], pbp, pnv, pav);
 		BPiece ppiece = fetch_piece(bbase, pbp, narrow);
+		// ... and the second one (a cell of more than NW blocks: the usual case), so that no step of a typical cell waits
+		// for memory inside the cell
+#ifndef BM_D2
+#define BM_D2 1
+#endif
+		constexpr bool D2 = BM_D2 && MODE != MODE_STORE;                     // (the COO variant has no registers left for it)
+		uint32_t qnv = 0; double qav = 0; BPiece qpiece;
+		if (D2 && ((X.cellI[1] - X.cellI[0]) >> 6) > (uint32_t)NW + wv) {     // wave-uniform
+			uint32_t qbp;
+			tile_lookup(X, tab, nzc, (X.cellI[0] >> 6) + NW + wv, X.cellI[1], qbp, qnv, qav);
+			qpiece = fetch_piece(bbase, qbp, narrow);
+		}
 		STAMP(0);
 		for (uint32_t c = 0; c < tile.ncells; ++c) {
 			STAMP_COUNT(11);
@@ -2724,6 +2737,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 				if (st > 0 && bl >= nblk) continue;                         // wave-uniform (step 0's piece is prefetched)
 				uint32_t nv; double av; BPiece piece;
 				if (st == 0) { nv = bl < nblk ? pnv : 0u; av = pav; piece = ppiece; }
+				else if (D2 && st == 1) { nv = qnv; av = qav; piece = qpiece; }
 				else {
 					uint32_t bp;
 					tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
@@ -2742,31 +2756,32 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			STAMP(2);
 			lds_barrier();                                          // the bitmap is complete
 			STAMP(3);
-			// the next cell's first block: lookup and B request issued now, consumed after this cell is done
-			if (c + 1 < tile.ncells) {                              // uniform
-				tile_lookup(X, tab, nzc, (i1 >> 6) + wv, X.cellI[c + 2], pbp, pnv, pav);
-				ppiece = fetch_piece(bbase, pbp, narrow);
-			}
-			// ---- 2. rank prefix of the bitmap words: thread t owns words [WPT t, WPT t + WPT)
+			// ---- 2. rank prefix of the bitmap words: thread t owns words [WPT t, WPT t + WPT); bpre holds the prefix INSIDE
+			// the wave's 64 WPT words, the waves' bases go to s_wbase after the barrier (every wave computes and writes the
+			// same eight values and reads back its own writes: no barrier needed for them)
 			uint32_t wcnt[WPT], mine = 0;
+			{
+				unsigned long long wd[WPT];
 #pragma unroll
-			for (int x = 0; x < WPT; ++x) {
-				const uint32_t w = tid * WPT + x;
-				wcnt[x] = w < nwords ? (uint32_t)__popcll(bm[w]) : 0u;
-				mine += wcnt[x];
+				for (int x = 0; x < WPT; ++x) wd[x] = bm[tid * WPT + x];      // (words beyond the cell's range are clean: zero)
+				// the next cell's first block(s): lookup and B request issued now, consumed after this cell is done
+				if (c + 1 < tile.ncells) {                              // uniform
+					const uint32_t i2 = X.cellI[c + 2];
+					tile_lookup(X, tab, nzc, (i1 >> 6) + wv, i2, pbp, pnv, pav);
+					ppiece = fetch_piece(bbase, pbp, narrow);
+					if (D2 && ((i2 - i1) >> 6) > (uint32_t)NW + wv) {        // wave-uniform
+						uint32_t qbp;
+						tile_lookup(X, tab, nzc, (i1 >> 6) + NW + wv, i2, qbp, qnv, qav);
+						qpiece = fetch_piece(bbase, qbp, narrow);
+					}
+				}
+#pragma unroll
+				for (int x = 0; x < WPT; ++x) { wcnt[x] = (uint32_t)__popcll(wd[x]); mine += wcnt[x]; }
 			}
 			const uint32_t inc = wave_inclusive_scan_u32(mine);
 			if (lane == 63) s_wtot[sflip][wv] = inc;
-			STAMP(4);
-			lds_barrier();
-			STAMP(5);
-			uint32_t base = 0, distinct = 0;
-#pragma unroll
-			for (int q = 0; q < NW; ++q) { const uint32_t t = s_wtot[sflip][q]; if (q < (int)wv) base += t; distinct += t; }
-			sflip ^= 1u;
-			distinct = (uint32_t)__builtin_amdgcn_readfirstlane((int)distinct);
 			{
-				uint32_t run = base + inc - mine;
+				uint32_t run = inc - mine;
 #pragma unroll
 				for (int x = 0; x < WPT; ++x) {
 					const uint32_t w = tid * WPT + x;
@@ -2774,6 +2789,17 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					run += wcnt[x];
 				}
 			}
+			STAMP(4);
+			lds_barrier();
+			STAMP(5);
+			uint32_t distinct;
+			{
+				const uint32_t t = lane < (unsigned)NW ? s_wtot[sflip][lane] : 0u;
+				const uint32_t ti = wave_inclusive_scan_u32(t);
+				if (lane < (unsigned)NW) s_wbase[lane] = ti - t;
+				distinct = (uint32_t)__builtin_amdgcn_readlane((int)ti, NW - 1);
+			}
+			sflip ^= 1u;
 			if (MODE == MODE_COUNT && !ep.sk_pos) {
 				// structural count: the distinct columns (scalek absent: every column is allowed); clean up and go on
 				if (tid == 0) sk.segcount[seg] = distinct;
@@ -2785,16 +2811,21 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			STAMP(4);
 			// ---- 3. accumulate by rank (the structural count needs no values: it walks the words directly)
 			if constexpr (MODE != MODE_COUNT) {
-				lds_barrier();                                      // prefix visible
-				STAMP(5);
 #pragma unroll
 				for (int st = 0; st < MAXST; ++st) {
+					if ((uint32_t)st * NW + wv >= nblk) continue;           // wave-uniform: no product in this step
+					// all the lookups of a step in flight together (an empty slot reads word 2047 & ... of the bitmap: harmless)
+					uint32_t pre[R], wb[R]; unsigned long long wd[R];
+#pragma unroll
+					for (int u = 0; u < R; ++u) {
+						const uint32_t w = (krel[st][u] >> 6) & (uint32_t)(BM_WORDS - 1);
+						pre[u] = bpre[w]; wb[u] = s_wbase[w / (64 * WPT)]; wd[u] = bm[w];
+					}
 #pragma unroll
 					for (int u = 0; u < R; ++u) {
 						const uint32_t rel = krel[st][u];
 						if (rel != 0xFFFFFFFFu) {
-							const uint32_t w = rel >> 6;
-							const uint32_t rank = (uint32_t)bpre[w] + (uint32_t)__popcll(bm[w] & ((1ull << (rel & 63u)) - 1ull));
+							const uint32_t rank = wb[u] + pre[u] + (uint32_t)__popcll(wd[u] & ((1ull << (rel & 63u)) - 1ull));
 							atomicAdd(&acc[rank], kval[st][u]);
 							colof[rank] = rel;
 						}
@@ -2809,14 +2840,22 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			// and the bitmap word of its column
 			if constexpr (MODE == MODE_DIGEST) {
 				unsigned long long cnt = 0; double vs = 0;
-				for (uint32_t i = tid; i < distinct; i += NT) {
-					const uint32_t rel = colof[i];
-					double v = acc[i];
-					acc[i] = 0.0;
-					bm[rel >> 6] = 0ull;
+				auto note = [&](uint32_t rel, double v) {
 					const int32_t col = (int32_t)(colbase + rel);
 					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, col, v, &v);
 					if (ok) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+				};
+				for (uint32_t i = tid; i < distinct; i += 2 * NT) {     // two ranks per trip: their LDS reads overlap
+					const uint32_t j = i + NT;
+					const bool two = j < distinct;
+					const uint32_t jj = two ? j : i;
+					const uint32_t rel0 = colof[i], rel1 = colof[jj];
+					const double v0 = acc[i], v1 = acc[jj];
+					acc[i] = 0.0;
+					bm[rel0 >> 6] = 0ull;
+					if (two) { acc[j] = 0.0; bm[rel1 >> 6] = 0ull; }
+					note(rel0, v0);
+					if (two) note(rel1, v1);
 				}
 				d_cnt += cnt; d_sum += vs;
 				if (sk.row_nnz) {
