@@ -2186,6 +2186,9 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		uint32_t wcount = 0;
 		constexpr unsigned long long MIXK = 0x9E3779B97F4A7C15ull;
 		unsigned long long X0 = ((((unsigned long long)(uint32_t)rowid) << 32) | (unsigned long long)(wbase + wv * GPW * 64u)) * MIXK;   // uniform
+		// (pinned to scalar registers: left to itself the compiler re-derives the product per group with v_mad_u64_u32)
+		X0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(X0 >> 32)) << 32) |
+			(unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)X0);
 		double r_sum = 0;
 #pragma unroll
 		for (int gi = 0; gi < GPW; ++gi) {
@@ -2204,7 +2207,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 				unsigned long long h = X0 + laneK;
 				h ^= h >> 29;
 				d_hash += ok ? h : 0ull;
-				r_sum += ok ? x : 0.0;
+				if (plain && !PAT) r_sum += x;                          // (a slot that is not emitted holds +-0)
+				else r_sum += ok ? x : 0.0;
 				X0 += 64ull * MIXK;
 			}
 		}
@@ -2619,8 +2623,8 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 	constexpr int NWORD = BM_ITEMS / 64;
 	constexpr int MAXST = (BM_MAXOUT / R + (int)TILE_LMAX + 64 + NT - 1) / NT;      // 64-item blocks of one cell per wave
 	constexpr int WPT = BM_WORDS / NT;       // bitmap words per thread in the scan (4)
-	__shared__ unsigned long long bm[BM_WORDS];
-	__shared__ uint16_t bpre[BM_WORDS];
+	__shared__ __attribute__((aligned(16))) unsigned long long bm[BM_WORDS];
+	__shared__ __attribute__((aligned(8))) uint16_t bpre[BM_WORDS];
 	__shared__ double acc[BM_MAXOUT];
 	__shared__ uint32_t colof[BM_MAXOUT];                       // column (relative to the cell's first) of every rank
 	__shared__ TileX<NT, NWORD> X;
@@ -2781,13 +2785,10 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			const uint32_t inc = wave_inclusive_scan_u32(mine);
 			if (lane == 63) s_wtot[sflip][wv] = inc;
 			{
-				uint32_t run = inc - mine;
-#pragma unroll
-				for (int x = 0; x < WPT; ++x) {
-					const uint32_t w = tid * WPT + x;
-					if (w < nwords) bpre[w] = (uint16_t)run;
-					run += wcnt[x];
-				}
+				// the thread's WPT prefixes in one 64-bit store (entries past the cell's words are never read)
+				static_assert(WPT == 4, "packed prefix store");
+				const uint32_t r0 = inc - mine, r1 = r0 + wcnt[0], r2 = r1 + wcnt[1], r3 = r2 + wcnt[2];
+				reinterpret_cast<uint2 *>(bpre)[tid] = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
 			}
 			STAMP(4);
 			lds_barrier();
@@ -2838,6 +2839,11 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			// ---- 4. emit in order: thread i takes rank i (perfectly balanced -- walking the set bits of the words instead
 			// leaves the barrier waiting for the thread with the fullest word: 94 vs 42 ms), cleans the accumulator entry
 			// and the bitmap word of its column
+			if constexpr (MODE != MODE_COUNT) {
+				// the bitmap is cleaned by the threads that own its words (two 16-byte stores where any bit was set) rather
+				// than word by word from the emission loop
+				if (mine) { uint4 *z = reinterpret_cast<uint4 *>(&bm[tid * WPT]); z[0] = make_uint4(0, 0, 0, 0); z[1] = make_uint4(0, 0, 0, 0); }
+			}
 			if constexpr (MODE == MODE_DIGEST) {
 				unsigned long long cnt = 0; double vs = 0;
 				auto note = [&](uint32_t rel, double v) {
@@ -2852,8 +2858,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					const uint32_t rel0 = colof[i], rel1 = colof[jj];
 					const double v0 = acc[i], v1 = acc[jj];
 					acc[i] = 0.0;
-					bm[rel0 >> 6] = 0ull;
-					if (two) { acc[j] = 0.0; bm[rel1 >> 6] = 0ull; }
+					if (two) acc[j] = 0.0;
 					note(rel0, v0);
 					if (two) note(rel1, v1);
 				}
@@ -2899,7 +2904,6 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 						rel = colof[i];
 						v = acc[i];
 						acc[i] = 0.0;
-						bm[rel >> 6] = 0ull;
 						ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v);
 					}
 					uint32_t at = i;
