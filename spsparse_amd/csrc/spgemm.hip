@@ -2753,7 +2753,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 						const uint32_t rel = piece.w[3 * u] - colbase;
 						krel[st][u] = rel;
 						if constexpr (MODE != MODE_COUNT) kval[st][u] = av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
-						atomicOr(&bm[rel >> 6], 1ull << (rel & 63u));
+						atomicOr(reinterpret_cast<uint32_t *>(bm) + (rel >> 5), 1u << (rel & 31u));      // (32-bit halves: half the bank traffic of a 64-bit or)
 					}
 				}
 			}
