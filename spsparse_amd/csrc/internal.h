@@ -116,6 +116,21 @@ namespace spsamd {
 void scan_exclusive_u32_i64(spsamd_ctx *c, const uint32_t *in, int64_t *out, size_t n);
 void scan_exclusive_u32_u32(spsamd_ctx *c, const uint32_t *in, uint32_t *out, size_t n);
 void scan_exclusive_u8_u32(spsamd_ctx *c, const uint8_t *in, uint32_t *out, size_t n);
+void scan_exclusive_u16_u32(spsamd_ctx *c, const uint16_t *in, uint32_t *out, size_t n);
+
+// The same for up to SCAN_BATCH_MAX arrays of one length in three launches (blockIdx.y = array): the symbolic phase
+// scans a dozen per-row counters of the heavy rows, and a launch is worth more than the work at that size.
+constexpr int SCAN_BATCH_MAX = 12;
+struct ScanBatch { const uint32_t *in[SCAN_BATCH_MAX]; uint32_t *out[SCAN_BATCH_MAX]; int count = 0;
+	void add(const uint32_t *i, uint32_t *o) { in[count] = i; out[count] = o; ++count; } };
+void scan_exclusive_u32_batch(spsamd_ctx *c, const ScanBatch &b, size_t n);
+
+// One device-to-host round trip for a list of 32-bit words scattered over device memory (host[i] = *p[i]).
+constexpr int WORD_LIST_MAX = 40;
+struct WordList { const uint32_t *p[WORD_LIST_MAX]; int count = 0;
+	int add(const void *q) { p[count] = (const uint32_t *)q; return count++; }
+	int add64(const void *q) { const int at = add(q); add((const uint32_t *)q + 1); return at; } };
+void read_back_words(spsamd_ctx *c, const WordList &w, uint32_t *host);
 
 // Stable LSD radix sort of (key, payload) pairs on key bits [0, key_bits).
 // Returns which of the two buffer pairs holds the result (0: keys0/pay0, 1: keys1/pay1).

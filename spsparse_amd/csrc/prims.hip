@@ -210,6 +210,109 @@ static void scan_exclusive(spsamd_ctx *c, const TIn *in, TOut *out, size_t n)
 void scan_exclusive_u32_i64(spsamd_ctx *c, const uint32_t *in, int64_t *out, size_t n) { scan_exclusive<uint32_t, int64_t>(c, in, out, n); }
 void scan_exclusive_u32_u32(spsamd_ctx *c, const uint32_t *in, uint32_t *out, size_t n) { scan_exclusive<uint32_t, uint32_t>(c, in, out, n); }
 void scan_exclusive_u8_u32(spsamd_ctx *c, const uint8_t *in, uint32_t *out, size_t n) { scan_exclusive<uint8_t, uint32_t>(c, in, out, n); }
+void scan_exclusive_u16_u32(spsamd_ctx *c, const uint16_t *in, uint32_t *out, size_t n) { scan_exclusive<uint16_t, uint32_t>(c, in, out, n); }
+
+// ---- batched: arrays b.in[y] -> b.out[y], y = blockIdx.y ----
+
+__global__ __launch_bounds__(SCAN_NT) void k_scan_tile_sums_batch(ScanBatch b, size_t n, uint32_t *sums, uint32_t ntiles)
+{
+	__shared__ uint32_t scratch[SCAN_NT / 64 + 1];
+	const uint32_t *in = b.in[blockIdx.y];
+	size_t base = (size_t)blockIdx.x * SCAN_TILE;
+	uint32_t s = 0;
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; ++q) {
+		size_t i = base + (size_t)q * SCAN_NT + threadIdx.x;
+		if (i < n) s += in[i];
+	}
+	s = wave_reduce_sum(s);
+	if (lane_id() == 0) scratch[wave_id()] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+		for (int w = 0; w < SCAN_NT / 64; ++w) t += scratch[w];
+		sums[(size_t)blockIdx.y * ntiles + blockIdx.x] = t;
+	}
+}
+
+// one workgroup per array: exclusive scan of its ntiles tile sums, in place
+__global__ __launch_bounds__(SCAN_NT) void k_scan_sums_batch(uint32_t *sums, uint32_t ntiles)
+{
+	__shared__ uint32_t scratch[SCAN_NT / 64 + 1];
+	uint32_t *a = sums + (size_t)blockIdx.x * ntiles;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < ntiles; base += SCAN_NT) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < ntiles ? a[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_exclusive_scan<uint32_t, SCAN_NT>(v, scratch, &tot);
+		if (i < ntiles) a[i] = carry + ex;
+		carry += tot;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(SCAN_NT) void k_scan_tiles_batch(ScanBatch b, size_t n, const uint32_t *tile_off, uint32_t ntiles)
+{
+	__shared__ uint32_t scratch[SCAN_NT / 64 + 1];
+	const uint32_t *in = b.in[blockIdx.y];
+	uint32_t *out = b.out[blockIdx.y];
+	size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+	uint32_t v[SCAN_ITEMS];
+	uint32_t s = 0;
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; ++q) {
+		size_t i = base + q;
+		v[q] = i < n ? in[i] : 0u;
+		s += v[q];
+	}
+	uint32_t ex = block_exclusive_scan<uint32_t, SCAN_NT>(s, scratch, (uint32_t *)nullptr);
+	uint32_t run = ex + tile_off[(size_t)blockIdx.y * ntiles + blockIdx.x];
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; ++q) {
+		size_t i = base + q;
+		if (i < n) {
+			out[i] = run;
+			run += v[q];
+			if (i == n - 1) out[n] = run;
+		}
+	}
+}
+
+void scan_exclusive_u32_batch(spsamd_ctx *c, const ScanBatch &b, size_t n)
+{
+	if (b.count == 0) return;
+	if (n == 0) {
+		for (int y = 0; y < b.count; ++y) fill_zero(c, b.out[y], sizeof(uint32_t));
+		return;
+	}
+	const size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+	uint32_t *sums = c->arena.get<uint32_t>(ntiles * (size_t)b.count);
+	k_scan_tile_sums_batch<<<dim3((unsigned)ntiles, (unsigned)b.count), dim3(SCAN_NT), 0, c->stream>>>(b, n, sums, (uint32_t)ntiles);
+	SPS_LAUNCH_CHECK();
+	k_scan_sums_batch<<<dim3((unsigned)b.count), dim3(SCAN_NT), 0, c->stream>>>(sums, (uint32_t)ntiles);
+	SPS_LAUNCH_CHECK();
+	k_scan_tiles_batch<<<dim3((unsigned)ntiles, (unsigned)b.count), dim3(SCAN_NT), 0, c->stream>>>(b, n, sums, (uint32_t)ntiles);
+	SPS_LAUNCH_CHECK();
+}
+
+__global__ void k_collect_words(WordList w, uint32_t *dst)
+{
+	const int i = (int)threadIdx.x;
+	if (i < w.count) dst[i] = *w.p[i];
+}
+
+void read_back_words(spsamd_ctx *c, const WordList &w, uint32_t *host)
+{
+	if (w.count == 0) return;
+	uint32_t *dev = c->arena.get<uint32_t>(WORD_LIST_MAX);
+	k_collect_words<<<dim3(1), dim3(64), 0, c->stream>>>(w, dev);
+	SPS_LAUNCH_CHECK();
+	uint32_t *h = (uint32_t *)c->host_staging(sizeof(uint32_t) * WORD_LIST_MAX);
+	SPS_HIP(hipMemcpyAsync(h, dev, sizeof(uint32_t) * (size_t)w.count, hipMemcpyDeviceToHost, c->stream));
+	SPS_HIP(hipStreamSynchronize(c->stream));
+	for (int i = 0; i < w.count; ++i) host[i] = h[i];
+}
 
 // ------------------------------------------------------------------ radix sort
 

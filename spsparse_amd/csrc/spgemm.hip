@@ -1603,7 +1603,7 @@ __global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwi
 // with a CSR row pointer per window: wptr[w * nrowb + k] .. [+1].  The working set of the
 // workgroups that are on window w is then |B_w| * 12 bytes plus a 4 * nrowb byte pointer slice,
 // and a row's pass over its A tuples (ascending k) moves forward through both.
-__global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_t nrowb, uint32_t nwin, uint32_t nwin1, uint32_t *cnt)
+__global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_t nrowb, uint32_t nwin, uint32_t nwin1, uint16_t *cnt)
 {
 	__shared__ uint32_t tile[64][65];
 	const uint32_t k0 = blockIdx.x * 64u, w0 = blockIdx.y * 64u;
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_
 	__syncthreads();
 	for (uint32_t wy = ty; wy < 64; wy += 4) {
 		const uint32_t w = w0 + wy, k = k0 + tx;
-		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = tile[tx][wy + 1] - tile[tx][wy];
+		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = (uint16_t)(tile[tx][wy + 1] - tile[tx][wy]);   // <= W tuples of one row in one window
 	}
 }
 
@@ -1855,7 +1855,7 @@ __global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *
 		for (int k = 0; k < NCLS + 2; ++k) if (np[k]) atomicAdd(&clsprod[k], np[k]);
 		nseg[r] = ordinal;
 		for (int kd = 0; kd < 2; ++kd) if (tk.k[kd].enabled) { tk.k[kd].ntc[h] = ntc[kd]; tk.k[kd].ntl[h] = ntl[kd]; }
-		if (alt_on) { if (alt_cur) ++alt_n; if (alt_n) atomicAdd(tk.alt_cells, (unsigned long long)alt_n); }
+		if (alt_on) { if (alt_cur) ++alt_n; if (alt_n) atomicAdd(tk.alt_cells, (unsigned long long)alt_n); if (ntc[0]) atomicAdd(tk.alt_cells + 1, (unsigned long long)ntc[0]); }
 	}
 }
 
@@ -3405,11 +3405,11 @@ static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32
 {
 	hipStream_t st = c->stream;
 	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
-	uint32_t *cnt = c->arena.get<uint32_t>(total);
+	uint16_t *cnt = c->arena.get<uint16_t>(total);
 	hv.wptr = c->arena.get<uint32_t>(total + 1);
 	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(hv.bwin, (uint32_t)nrowb, hv.nwin, hv.nwin1, cnt);
 	SPS_LAUNCH_CHECK();
-	scan_exclusive_u32_u32(c, cnt, hv.wptr, total);
+	scan_exclusive_u16_u32(c, cnt, hv.wptr, total);
 	hv.btw = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);
 	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
 	SPS_LAUNCH_CHECK();
@@ -3462,7 +3462,6 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
 	// (a window between dense_min and cell_cap products becomes a dense cell; smaller ones are grouped up to cell_cap)
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
-	fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
 	hv.tb.enabled = !c->tune.no_tiles;
 	// Tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles v2.
 	// ORDERED runs on the first generation, EXACT_PATTERN on the hash tiles v2 (the variants that exist); otherwise the
@@ -3485,7 +3484,6 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	for (TileBases *t : {&hv.tb, &hv.tb2}) {
 		t->ntc = c->arena.get<uint32_t>(hv.n); t->ntl = c->arena.get<uint32_t>(hv.n);
 		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
-		fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t));
 	}
 	auto count_pass = [&]() {
 		fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
@@ -3502,27 +3500,34 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		// cut; only where that one wins is the pass repeated.
 		set_scheme(0);
 		hv.alt_cap = (uint32_t)(TILE_T / 2); hv.alt_span = 0;
-		hv.alt_cells = c->arena.get<unsigned long long>(1);
-		fill_zero(c, hv.alt_cells, sizeof(unsigned long long));
+		hv.alt_cells = c->arena.get<unsigned long long>(2);          // [0] cells of the hash scheme, [1] of the bitmap scheme
+		fill_zero(c, hv.alt_cells, 2 * sizeof(unsigned long long));
 		count_pass();
-		scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
-		const uint32_t cells_bm = read_back(c, hv.tb.tcbase + hv.n);
-		const unsigned long long cells_hash = read_back(c, hv.alt_cells);
+		WordList wl; wl.add64(hv.alt_cells); wl.add64(hv.alt_cells + 1);
+		uint32_t hw[4];
+		read_back_words(c, wl, hw);
+		const unsigned long long cells_hash = (unsigned long long)hw[0] | ((unsigned long long)hw[1] << 32);
+		const unsigned long long cells_bm = (unsigned long long)hw[2] | ((unsigned long long)hw[3] << 32);
 		hv.alt_cells = nullptr;
-		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %u hash %llu\n", cells_bm, cells_hash);
-		if ((uint64_t)cells_bm * 115u > (uint64_t)cells_hash * 100u) { set_scheme(2); count_pass(); }
+		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %llu hash %llu\n", cells_bm, cells_hash);
+		if (cells_bm * 115u > cells_hash * 100u) { set_scheme(2); count_pass(); }
 	} else count_pass();
-	for (int k = 0; k < NCLS; ++k) scan_exclusive_u32_u32(c, hv.cnt.base[k], hv.base.base[k], hv.n);
-	scan_exclusive_u32_u32(c, hv.tb.ntc, hv.tb.tcbase, hv.n);
-	scan_exclusive_u32_u32(c, hv.tb.ntl, hv.tb.tlbase, hv.n);
-	scan_exclusive_u32_u32(c, hv.tb2.ntc, hv.tb2.tcbase, hv.n);
-	scan_exclusive_u32_u32(c, hv.tb2.ntl, hv.tb2.tlbase, hv.n);
-	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = read_back(c, hv.base.base[k] + hv.n);
-	hv.ntcell = read_back(c, hv.tb.tcbase + hv.n);
-	hv.ntile = read_back(c, hv.tb.tlbase + hv.n);
-	hv.ntcell2 = read_back(c, hv.tb2.tcbase + hv.n);
-	hv.ntile2 = read_back(c, hv.tb2.tlbase + hv.n);
-	for (int k = 0; k < NCLS + 2; ++k) hv.clsprod[k] = read_back(c, clsprod + k);
+	// every per-row counter of the grouping scanned in one batch, every total read back in one round trip
+	ScanBatch sb;
+	for (int k = 0; k < NCLS; ++k) sb.add(hv.cnt.base[k], hv.base.base[k]);
+	sb.add(hv.tb.ntc, hv.tb.tcbase); sb.add(hv.tb.ntl, hv.tb.tlbase);
+	sb.add(hv.tb2.ntc, hv.tb2.tcbase); sb.add(hv.tb2.ntl, hv.tb2.tlbase);
+	static_assert(NCLS + 4 <= SCAN_BATCH_MAX && NCLS + 4 + 2 * (NCLS + 2) <= WORD_LIST_MAX, "batch sizes");
+	scan_exclusive_u32_batch(c, sb, hv.n);
+	WordList wl;
+	for (int k = 0; k < NCLS; ++k) wl.add(hv.base.base[k] + hv.n);
+	wl.add(hv.tb.tcbase + hv.n); wl.add(hv.tb.tlbase + hv.n); wl.add(hv.tb2.tcbase + hv.n); wl.add(hv.tb2.tlbase + hv.n);
+	for (int k = 0; k < NCLS + 2; ++k) wl.add64(clsprod + k);
+	uint32_t hw[WORD_LIST_MAX];
+	read_back_words(c, wl, hw);
+	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = hw[k];
+	hv.ntcell = hw[NCLS]; hv.ntile = hw[NCLS + 1]; hv.ntcell2 = hw[NCLS + 2]; hv.ntile2 = hw[NCLS + 3];
+	for (int k = 0; k < NCLS + 2; ++k) hv.clsprod[k] = (unsigned long long)hw[NCLS + 4 + 2 * k] | ((unsigned long long)hw[NCLS + 5 + 2 * k] << 32);
 	if ((hv.ncell[CLS_DENSE] || hv.ntile2) && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
 }
 
