@@ -3020,6 +3020,10 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 		}
 		TileTab<NWORD / 64> tab;
 		tile_tables(X, tab);
+		// first block of cell 0, prefetched like every later cell's (requested while the previous cell is claimed)
+		uint32_t pbp, pnv; double pav;
+		tile_lookup(X, tab, nzc, (X.cellI[0] >> 6) + wv, X.cellI[1], pbp, pnv, pav);
+		BPiece ppiece = fetch_piece(bbase, pbp, narrow);
 
 		for (uint32_t c = 0; c < tile.ncells; ++c) {
 			const uint32_t i0 = X.cellI[c], i1 = X.cellI[c + 1];      // multiples of 64; i1 = next cell's (aligned) start
@@ -3036,9 +3040,13 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 				for (int u = 0; u < R; ++u) ks[st][u] = (uint32_t)W + lane;
 				const uint32_t bl = (uint32_t)st * NW + wv;
 				if (bl < nblk) {                                            // wave-uniform
-					uint32_t bp, nv; double av;
-					tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
-					const BPiece piece = fetch_piece(bbase, bp, narrow);
+					uint32_t nv; double av; BPiece piece;
+					if (st == 0) { nv = pnv; av = pav; piece = ppiece; }
+					else {
+						uint32_t bp;
+						tile_lookup(X, tab, nzc, (i0 >> 6) + bl, i1, bp, nv, av);
+						piece = fetch_piece(bbase, bp, narrow);
+					}
 #pragma unroll
 					for (int u = 0; u < R; ++u) {
 						const uint32_t slot = (uint32_t)u < nv ? piece.w[3 * u] - wbase : (uint32_t)W + lane;
@@ -3049,19 +3057,27 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 				}
 			}
 			lds_barrier();                                          // every product of the cell is in the accumulator
-			// ---- claim: exchange the slot with 0; a non-zero answer makes this thread the tuple's owner
+			if (c + 1 < tile.ncells) {                              // uniform: the next cell's first block, in flight during the claim
+				tile_lookup(X, tab, nzc, (i1 >> 6) + wv, X.cellI[c + 2], pbp, pnv, pav);
+				ppiece = fetch_piece(bbase, pbp, narrow);
+			}
+			// ---- claim: exchange the slot with 0; a non-zero answer makes this thread the tuple's owner.  The R exchanges
+			// of a step are in flight together (a dump slot is exchanged like any other: its answer is not looked at)
 			unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
 			uint32_t mycount = 0; double mysum = 0.0;
 #pragma unroll
 			for (int st = 0; st < MAXST; ++st) {
 				if ((uint32_t)st * NW + wv < nblk) {                        // wave-uniform
+					unsigned long long olds[R];
+#pragma unroll
+					for (int u = 0; u < R; ++u) olds[u] = atomicExch(&acc64[ks[st][u]], 0ull);
 #pragma unroll
 					for (int u = 0; u < R; ++u) {
 						const uint32_t slot = ks[st][u];
 						bool own = false;
 						double v = 0.0;
 						if (slot < (uint32_t)W) {
-							const unsigned long long old = atomicExch(&acc64[slot], 0ull);
+							const unsigned long long old = olds[u];
 							v = __longlong_as_double((long long)old);
 							const int32_t col = (int32_t)(wbase + slot);
 							if (MODE == MODE_COUNT) own = (v != 0) && col_allowed(ep, col);
