@@ -24,19 +24,21 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 	uint64_t nrow, uint64_t ncol, int zero_nan, uint32_t *flags)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	int32_t r = major[i], c = minor[i];
 	uint32_t f = 0;
-	if (r < 0 || (uint64_t)r >= nrow || c < 0 || (uint64_t)c >= ncol) f |= 1u;
-	double v = val[i];
-	if (v == 0 || (zero_nan && v != v)) f |= 2u;
-	if (i > 0) {
-		int32_t pr = major[i - 1], pc = minor[i - 1];
-		if (!(pr < r || (pr == r && pc < c))) f |= 2u;
+	if (i < n) {
+		int32_t r = major[i], c = minor[i];
+		if (r < 0 || (uint64_t)r >= nrow || c < 0 || (uint64_t)c >= ncol) f |= 1u;
+		double v = val[i];
+		if (v == 0 || (zero_nan && v != v)) f |= 2u;
+		if (i > 0) {
+			int32_t pr = major[i - 1], pc = minor[i - 1];
+			if (!(pr < r || (pr == r && pc < c))) f |= 2u;
+		}
 	}
-	// almost every thread of an unsorted operand raises bit 1: test the flag word before the
-	// atomic so the common case is a cached read, not a serialised same-address atomic
-	if (f && (*(volatile uint32_t *)flags & f) != f) atomicOr(flags, f);
+	// almost every thread of an unsorted operand raises bit 1: one lane per wave speaks for it, and tests the flag
+	// word before the atomic (16 M reads of one address were most of this kernel's time)
+	const uint32_t wf = (__ballot(f & 1u) ? 1u : 0u) | (__ballot(f & 2u) ? 2u : 0u);
+	if (wf && lane_id() == 0 && (*(volatile uint32_t *)flags & wf) != wf) atomicOr(flags, wf);
 }
 
 __global__ void k_build_keys(const int32_t *major, const int32_t *minor, size_t n, int minor_bits, uint64_t *keys)

@@ -690,8 +690,8 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 // longest row of a dense row pointer
 __global__ void k_max_rowlen(const uint32_t *ptr, uint64_t nrow, uint32_t *out)
 {
-	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t v = r < nrow ? ptr[r + 1] - ptr[r] : 0u;
+	uint32_t v = 0;
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (uint64_t)gridDim.x * blockDim.x) v = max(v, ptr[r + 1] - ptr[r]);
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
 	// (same-address atomics serialise: only a wave that would raise the maximum issues one)
@@ -3724,9 +3724,9 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		const uint32_t *aptr = same ? bptr : dense_rowptr(c, A, 0);
 		uint32_t *mx = c->arena.get<uint32_t>(2);
 		fill_zero(c, mx, 2 * sizeof(uint32_t));
-		k_max_rowlen<<<dim3(grid_for(A.nrow)), dim3(256), 0, st>>>(aptr, A.nrow, mx);
+		k_max_rowlen<<<dim3(std::min(grid_for(A.nrow), 1024u)), dim3(256), 0, st>>>(aptr, A.nrow, mx);
 		SPS_LAUNCH_CHECK();
-		if (!same) { k_max_rowlen<<<dim3(grid_for(B.nrow)), dim3(256), 0, st>>>(bptr, B.nrow, mx + 1); SPS_LAUNCH_CHECK(); }
+		if (!same) { k_max_rowlen<<<dim3(std::min(grid_for(B.nrow), 1024u)), dim3(256), 0, st>>>(bptr, B.nrow, mx + 1); SPS_LAUNCH_CHECK(); }
 		struct { uint32_t a, b; } hm = read_back(c, (const decltype(hm) *)mx);
 		if (same) hm.b = hm.a;
 		if ((uint64_t)hm.a * hm.b <= 64 && A.nrow < (uint64_t(1) << 32)) {
