@@ -1721,8 +1721,16 @@ constexpr int NCLS = 5;
 constexpr int CLS_DENSE = NCLS - 1;
 constexpr uint32_t CELL_CAP = 4096;      // largest hash cell (T = 8192)
 constexpr uint32_t CELL_CAP_DEFAULT = 2048;      // greedy grouping target of the hash cells (measured best on R-MAT scale-20)
-constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // a single window above this becomes a dense cell
-constexpr uint32_t DIRECT_MIN_DEFAULT = 1536;    // a single window of a tile row above this becomes a direct cell (measured: below ~1000 the hash tile wins)
+// A single window above DENSE_MIN products becomes a dense cell.  Measured on R-MAT scale 20 with the bitmap tiles as they
+// are now (cfg2, ms): 1792 -> 80.9, 2048 -> 79.0, 2560 -> 79.0, 2816 -> 78.5, 3072 -> 78.1 .. 78.6, 3328 -> 79.0, 3584 -> 80.7,
+// 4096 -> 81.4 (the tiles take a 3000-product window at 4.3 ps per product, the dense kernel -- which scans all W slots
+// -- needs more products than that to get to its 2.6).
+constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // ... with hash tiles (2048-product cells; scale 23: 2.25 s against 2.38 s at 3072)
+constexpr uint32_t DENSE_MIN_BITMAP = 3072;      // ... with bitmap tiles (4096-product cells)
+// A single window of a tile row above DIRECT_MIN products becomes a direct cell (k_direct_tiles).  OFF by default (>= the
+// dense threshold): the direct cells paid while a hash / bitmap tile cell cost 8 .. 10 k cycles (-0.6 ms at 1536); against
+// today's bitmap tiles they lose (cfg2: 80.4 with direct cells above 1536 products, 79.0 without; 1024 -> 86.0).
+constexpr uint32_t DIRECT_MIN_DEFAULT = 4096;
 __device__ __forceinline__ int hash_class(uint32_t prods) { return prods <= 512 ? 0 : (prods <= 1536 ? 1 : (prods <= 2048 ? 2 : 3)); }
 
 struct CellBases { uint32_t *base[NCLS]; };      // per heavy row: first cell index in each class list
@@ -3483,8 +3491,10 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	// ORDERED runs on the first generation, EXACT_PATTERN on the hash tiles v2 (the variants that exist); otherwise the
 	// choice is made per call below, by counting the cells either scheme would cut.
 	const bool free_choice = !ordered && !pattern && c->tune.tiles_v1 == 0;
+	const bool user_dense_min = c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP;
 	auto set_scheme = [&](int scheme) {
 		hv.tiles2 = scheme;
+		if (!user_dense_min) hv.dense_min = scheme == 0 && hv.tb.enabled ? DENSE_MIN_BITMAP : DENSE_MIN_DEFAULT;
 		hv.tb.by_items = scheme != 1 ? 1 : 0;
 		hv.tb.pb = scheme != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
 		hv.span_cap = scheme == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
