@@ -1726,6 +1726,7 @@ constexpr uint32_t CELL_CAP_DEFAULT = 2048;      // greedy grouping target of th
 // 4096 -> 81.4 (the tiles take a 3000-product window at 4.3 ps per product, the dense kernel -- which scans all W slots
 // -- needs more products than that to get to its 2.6).
 constexpr uint32_t DENSE_MIN_DEFAULT = 2048;     // ... with hash tiles (2048-product cells; scale 23: 2.25 s against 2.38 s at 3072)
+constexpr uint32_t LONG_DENSE_MIN_DEFAULT = 1024; // ... for the rows too long for a tile (heavy_prepare)
 constexpr uint32_t DENSE_MIN_BITMAP = 3072;      // ... with bitmap tiles (4096-product cells)
 // A single window of a tile row above DIRECT_MIN products becomes a direct cell (k_direct_tiles).  OFF by default (>= the
 // dense threshold): the direct cells paid while a hash / bitmap tile cell cost 8 .. 10 k cycles (-0.6 ms at 1536); against
@@ -3500,7 +3501,19 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		hv.span_cap = scheme == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	};
 	set_scheme(ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : 0)));
-	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : 0u;
+	// Rows too long for a tile: a hash-class cell of theirs reads B in row-major pieces of 4.4 tuples on average -- 6x the
+	// algorithmic bytes from HBM at line granularity (FETCH_SIZE of k_hash<3072>: 14.8 GB for 2.5 GB) -- while the dense kernel
+	// reads the window-major copy.  Their windows go to k_dense from LONG_DENSE_MIN products on.  R-MAT A*A, ms per step:
+	//   threshold   scale 19   scale 20 (cfg2)   scale 21
+	//     2048        26.9        78.1             251 (1536: 247.5)
+	//     1024         -          76.9             250.6
+	//      512        27.0        76.8             260.9
+	//      128        27.2        76.5             272.3
+	// (at scale 21 the same rows spread over twice the windows: a dense cell's walk over the row's A tuples and its scan of
+	// all W slots buy half the products).  1024 keeps most of scale 20's gain and costs scale 21 about 1 %.
+	// (8192-column windows only: the 16384-column dense kernel runs one workgroup per CU and wants full windows -- scale 23:
+	// 2.49 s with 128, 2.40 with 512, 2.26 with the general threshold)
+	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : (hv.W == 8192 ? LONG_DENSE_MIN_DEFAULT : 0u);
 	hv.long_cap = c->tune.long_cap > 0 ? (uint32_t)std::min<int>(c->tune.long_cap, (int)CELL_CAP) : 0u;
 	hv.tb2.by_items = 1;
 	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
