@@ -3532,11 +3532,11 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	};
 	if (free_choice && hv.tb.enabled) {
 		// Bitmap tiles hold 4096 products per cell but at most 16 windows of columns; hash tiles 2048 products over any
-		// range.  Per-cell bookkeeping is what the tile kernels' time is, so the scheme that cuts clearly fewer cells wins
-		// (break-even measured near 1.15 hash cells per bitmap cell): R-MAT scale 20 takes the bitmap tiles (3.22 M against
-		// 3.85 M cells: 42.0 vs 42.8 ms), scale 23 -- sparse rows spread over 512 windows, 150 M against 65 M cells -- the
-		// hash tiles (0.96 vs 1.35 s).  The counting pass of the bitmap scheme also counts the cells the hash scheme would
-		// cut; only where that one wins is the pass repeated.
+		// range.  Per-cell bookkeeping is most of a tile kernel's time, so the scheme that cuts clearly fewer cells wins;
+		// break-even measured near 1.4 bitmap cells per hash cell (R-MAT A*A: scale 20, 3.22 M against 3.85 M cells: bitmap,
+		// 34.8 vs 39+ ms; scale 21, 11.4 M against 12.2 M: bitmap, 236 vs 247 ms; scale 22, 42.6 M against 29.8 M: 727 vs
+		// 731 ms; scale 23 -- sparse rows spread over 512 windows, 150 M against 65 M -- hash, 0.95 vs 1.35 s).  The counting
+		// pass of the bitmap scheme also counts the cells the hash scheme would cut; only where that one wins is it repeated.
 		set_scheme(0);
 		hv.alt_cap = (uint32_t)(TILE_T / 2); hv.alt_span = 0;
 		hv.alt_cells = c->arena.get<unsigned long long>(2);          // [0] cells of the hash scheme, [1] of the bitmap scheme
@@ -3549,7 +3549,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		const unsigned long long cells_bm = (unsigned long long)hw[2] | ((unsigned long long)hw[3] << 32);
 		hv.alt_cells = nullptr;
 		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %llu hash %llu\n", cells_bm, cells_hash);
-		if (cells_bm * 115u > cells_hash * 100u) { set_scheme(2); count_pass(); }
+		if (cells_bm * 100u > cells_hash * 140u) { set_scheme(2); count_pass(); }
 	} else count_pass();
 	// every per-row counter of the grouping scanned in one batch, every total read back in one round trip
 	ScanBatch sb;
