@@ -526,6 +526,43 @@ def test_coo_emission_paths_agree(ctx, path):
     assert got[3].cells_hash > 0 and got[3].rows_mid > 0
 
 
+@pytest.mark.parametrize("knobs", [
+    {"tiles_v1": 1}, {"tiles_v1": 2}, {"tiles_v1": 3}, {"no_tiles": 1},
+    {"direct_min": 1024}, {"direct_min": 1024, "tiles_v1": 2},
+    {"dense_min": 1024, "long_dense_min": 64}, {"dense_min": 4096, "long_dense_min": 4096},
+], ids=lambda k: ",".join("%s=%d" % kv for kv in k.items()))
+def test_every_cell_scheme_against_the_oracle(ctx, knobs):
+    """The kernels a default call no longer picks on this matrix stay covered: each tile scheme (first-generation hash
+    tiles, hash tiles v2, bitmap-rank tiles, no tiles at all), the direct cells (off by default since round 2) and the
+    extremes of the dense thresholds, forced through the tuning knobs -- the same tuples in the same order as the
+    row-wise oracle, and the same digest."""
+    from spsparse_amd import capi
+    a = wl.rmat(15, seed=4)
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    for k, v in knobs.items():
+        ctx.set_tuning(k, v)
+    try:
+        got = _dev(ctx, A, A)
+        _, _, _, d = _dev(ctx, A, A, sink=capi.SINK_DIGEST)
+    finally:
+        for k in knobs:
+            ctx.set_tuning(k, 0)
+    _check(got, want)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s_) <= 1e-11 * abs(s_)
+    res = got[3]
+    assert res.rows_heavy > 0
+    if "direct_min" in knobs:
+        assert res.products_direct > 0
+    else:
+        assert res.products_direct == 0                     # off by default
+    if knobs.get("no_tiles"):
+        assert res.products_tiles == 0
+    elif "dense_min" not in knobs:
+        assert res.products_tiles > 0
+
+
 @pytest.mark.parametrize("tA,tB", [(".", "."), ("T", "."), (".", "T"), ("T", "T")])
 def test_heavy_rows_with_scales_and_flags(ctx, tA, tB):
     """Scale vectors (absent indices, zero scales), C != 1 and 'T' flags on an R-MAT product whose rows
