@@ -151,8 +151,8 @@ typedef struct {
 	uint64_t rows_light, rows_mid, rows_heavy;
 	uint64_t products_light, products_mid, products_heavy;
 	uint64_t tuples_light, tuples_mid, tuples_heavy;      /* A tuples in the rows of each class */
-	/* the heavy rows' hash-class cells by kernel: tiles (rows with <= 256 A tuples: hash / bitmap tiles), direct tiles;
-	 * the rest of ms_heavy - ms_dense is the windowed k_hash of the longer rows */
+	/* the heavy rows' hash-class cells by kernel: tiles (rows with <= 256 A tuples: hash / bitmap tiles), direct tiles
+	 * (off by default: 0); the rest of ms_heavy - ms_dense is the windowed k_hash of the longer rows */
 	float ms_tiles, ms_direct;
 	uint64_t products_tiles, products_direct;
 } spsamd_result;
@@ -167,10 +167,20 @@ const char *spsamd_last_error(const spsamd_ctx *ctx);
 /* pre-size the workspace (bytes); optional, it grows on demand otherwise */
 int spsamd_ctx_reserve(spsamd_ctx *ctx, size_t workspace_bytes, size_t output_tuples);
 const char *spsamd_version(void);
-/* Developer knobs ("window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path",
- * "bwin_budget_mb"; value 0 = default).  They select between equivalent kernels / tile sizes: the result
- * of a multiply is the same for every setting.  The environment variables of the same purpose
- * (SPSAMD_W ...) are read once, inside spsamd_ctx_create; nothing reads the environment later. */
+/* Developer knobs (value 0 = default).  They select between equivalent kernels / cell sizes: the result of a
+ * multiply is the same for every setting (tests/test_gpu_parity.py forces each in turn).
+ *   window          8192 | 16384      column-window width of the heavy rows (default: 16384 when ncol > 2^21)
+ *   cell_cap        64..4096          grouping target of the hash cells (2048)
+ *   dense_min       64..4096          a window above this many products is a dense cell (3072 with bitmap tiles, else 2048)
+ *   long_dense_min  > 0               the same for rows of more than 256 A tuples (1024 at 8192-column windows)
+ *   long_cap        > 0               grouping target of those rows' hash cells (cell_cap)
+ *   direct_min      > 0               a window of a tile row above this is a direct cell (off: >= dense_min)
+ *   tiles_v1        1 | 2 | 3         hash tiles r01 | hash tiles v2 | bitmap-rank tiles (default: chosen per call)
+ *   no_tiles, no_wmajor, xcd          1: no tiles | no window-major copy of B | XCD-partitioned cell lists
+ *   emit_path       1 | 2             COO order of a hash cell: LDS radix sort | bitonic network (default: by cell width)
+ *   light_path      1                 binned light kernels even where every row is light
+ * The environment variables of the same purpose (SPSAMD_W ...) are read once, inside spsamd_ctx_create; nothing reads
+ * the environment later.  Unknown names: SPSAMD_EINVAL. */
 int spsamd_ctx_set_tuning(spsamd_ctx *ctx, const char *name, long value);
 
 /*
