@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--sink", default="digest")
     ap.add_argument("--flags", type=int, default=0, help="sink flags (2 ordered, 8 exact pattern)")
+    ap.add_argument("--signed", action="store_true", help="flip the sign of half of the operand's values (cancellation: the EXACT_PATTERN paths)")
     ap.add_argument("variants", nargs="*", default=["base"])
     args = ap.parse_args()
     import torch
@@ -38,6 +39,10 @@ def main():
                 ctx.set_tuning(k, int(v))
         w = bench.Workload(torch, capi, ctx, dev, args.workload, args.scale, args.grid, 1, args.sink)
         w.flags = args.flags
+        if args.signed:
+            g = torch.Generator(device=dev); g.manual_seed(7)
+            w.t[2].mul_(torch.where(torch.rand(w.t[2].numel(), device=dev, generator=g) < 0.5, -1.0, 1.0))
+            torch.cuda.synchronize()
         out, results = bench.run_workload(torch, w, args.steps, 1)
         st = out["stage_ms"]
         dig = out.get("digest", {}).get("hash"), tuple(out["nnz_c"])

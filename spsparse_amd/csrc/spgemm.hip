@@ -199,24 +199,53 @@ __device__ __forceinline__ double pat_threshold(const PatCell *cell, uint32_t ns
 	return 8.0 * (double)nseg * 0x1p-53 * S;
 }
 // The reference's own sum for output (row of A tuples [beg, end), column col): ascending k, `sum += a*b`
-// (multiply_sparse.hpp:219-236).  One lane; used for the rare slots pat_threshold singles out.
-__device__ double ordered_sum(const RowMeta &m, uint32_t beg, uint32_t end, int32_t col)
+// (multiply_sparse.hpp:219-236), for the rare slots pat_threshold singles out.  Evaluated by a whole wave
+// (every lane must call it, with wave-uniform arguments): the lanes look up 64 A
+// tuples' B rows at a time, then the terms that exist are added in ascending position -- the reference's order -- with
+// wave-uniform lane reads.  A re-evaluation by ONE lane walks the row's tuples one dependent binary search after the
+// other: 17 ms for a row of 1000 tuples, and a hub row has tens of thousands.
+__device__ double ordered_sum_wave(const RowMeta &m, uint32_t beg, uint32_t end, int32_t col)
 {
 	double sum = 0.0;
-	for (uint32_t e = beg; e < end; ++e) {
-		const int32_t k = m.acol[e];
-		uint32_t lo = m.bptr[k];
-		const uint32_t top = m.bptr[k + 1];
-		uint32_t hi = top;
-		while (lo < hi) {
-			const uint32_t mid = lo + ((hi - lo) >> 1);
-			if (m.btup_rm[mid].col < col) lo = mid + 1; else hi = mid;
+	for (uint32_t base = beg; base < end; base += 64u) {
+		const uint32_t e = base + lane_id();
+		double term = 0.0;
+		bool has = false;
+		if (e < end) {
+			const int32_t k = m.acol[e];
+			uint32_t lo = m.bptr[k];
+			const uint32_t top = m.bptr[k + 1];
+			uint32_t hi = top;
+			while (lo < hi) {
+				const uint32_t mid = lo + ((hi - lo) >> 1);
+				if (m.btup_rm[mid].col < col) lo = mid + 1; else hi = mid;
+			}
+			if (lo < top && m.btup_rm[lo].col == col) { term = m.aval[e] * btup_val(m.btup_rm[lo]); has = true; }
 		}
-		if (lo < top && m.btup_rm[lo].col == col) sum += m.aval[e] * btup_val(m.btup_rm[lo]);
+		unsigned long long hm = __ballot(has);
+		while (hm) {                                                // uniform: ascending e
+			const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)hm) - 1);
+			hm &= hm - 1ull;
+			const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(term), l), __builtin_amdgcn_readlane(__double2loint(term), l));
+			sum += t;
+		}
 	}
 	return sum;
 }
-#define PAT_FIX(x, col_) do { if (PAT && !(fabs(x) > pthr)) (x) = ordered_sum(m, pbeg, pend, (col_)); } while (0)
+// x of the lanes with `need` set is replaced by the reference's sum for (the cell's row, that lane's column).  Every lane
+// of the wave must call it (converged); beg / end wave-uniform.
+__device__ __forceinline__ double pat_fix_wave(bool need, double x, int32_t col, const RowMeta &m, uint32_t beg, uint32_t end)
+{
+	unsigned long long mask = __ballot(need);
+	while (mask) {                                                  // uniform
+		const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)mask) - 1);
+		mask &= mask - 1ull;
+		const int32_t c = __builtin_amdgcn_readlane(col, l);
+		const double r = ordered_sum_wave(m, beg, end, c);
+		if ((int)lane_id() == l) x = r;
+	}
+	return x;
+}
 
 // Workgroup-wide digest accumulation: one set of atomics per workgroup, spread
 // over DIGEST_SLOTS accumulators so no address becomes a serial hot spot.
@@ -1138,14 +1167,18 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		if (tid == 0) sk.segcount[seg] = total;
 	} else if (MODE == MODE_DIGEST) {
 		unsigned long long cnt = 0; double vs = 0;
-		for (uint32_t i = tid; i < nocc; i += NT) {
-			uint32_t h = occ[i];
-			int32_t col = h_key[h];
+		for (uint32_t base = 0; base < nocc; base += NT) {                 // (uniform trips: pat_fix_wave wants whole waves)
+			const uint32_t i = base + tid;
+			const bool valid = i < nocc;
+			const uint32_t h = valid ? occ[i] : 0u;
+			const int32_t col = valid ? h_key[h] : 0;
 			double v;
-			double x = h_val[h];
-			PAT_FIX(x, col);
-			if (emit_value(ep, a_scale, col, x, &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
-			h_key[h] = -1; h_val[h] = 0.0;
+			double x = valid ? h_val[h] : 0.0;
+			if (PAT) x = pat_fix_wave(valid && !(fabs(x) > pthr), x, col, m, pbeg, pend);
+			if (valid) {
+				if (emit_value(ep, a_scale, col, x, &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+				h_key[h] = -1; h_val[h] = 0.0;
+			}
 		}
 		d.cnt += cnt; d.sum += vs;
 		if (sk.row_nnz) {
@@ -1175,12 +1208,13 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			for (int r = 0; r < EMAX; ++r) {
 				rel[r] = 0xFFFFFFFFu; slot[r] = 0;
 				const uint32_t i = r * NT + tid;
-				if (i < nocc) {
-					const uint32_t h = occ[i];
-					const int32_t col = h_key[h];
+				const bool valid = i < nocc;
+				const uint32_t h = valid ? occ[i] : 0u;
+				const int32_t col = valid ? h_key[h] : 0;
+				double x = valid ? h_val[h] : 0.0;
+				if (PAT) x = pat_fix_wave(valid && !(fabs(x) > pthr), x, col, m, pbeg, pend);
+				if (valid) {
 					double v = 0;
-					double x = h_val[h];
-					PAT_FIX(x, col);
 					const bool ok = emit_value(ep, a_scale, col, x, &v);
 					h_key[h] = -1;
 					h_val[h] = ok ? v : 0.0;
@@ -1219,12 +1253,13 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			for (uint32_t base = 0; base < nocc; base += NT) {
 				uint32_t i = base + tid;
 				bool ok = false;
-				int32_t col = 0;
-				if (i < nocc) {
-					uint32_t h = occ[i]; col = h_key[h];
+				const bool valid = i < nocc;
+				const uint32_t h = valid ? occ[i] : 0u;
+				const int32_t col = valid ? h_key[h] : 0;
+				double x = valid ? h_val[h] : 0.0;
+				if (PAT) x = pat_fix_wave(valid && !(fabs(x) > pthr), x, col, m, pbeg, pend);
+				if (valid) {
 					double v = 0;
-					double x = h_val[h];
-					PAT_FIX(x, col);
 					ok = emit_value(ep, a_scale, col, x, &v);
 					h_key[h] = -1;
 					h_val[h] = ok ? v : 0.0;
@@ -1253,12 +1288,13 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		for (uint32_t base = 0; base < nocc; base += NT) {
 			uint32_t i = base + tid;
 			bool ok = false;
-			uint32_t h = 0; int32_t col = 0;
-			if (i < nocc) {
-				h = occ[i]; col = h_key[h];
+			const bool valid = i < nocc;
+			const uint32_t h = valid ? occ[i] : 0u;
+			const int32_t col = valid ? h_key[h] : 0;
+			double x = valid ? h_val[h] : 0.0;
+			if (PAT) x = pat_fix_wave(valid && !(fabs(x) > pthr), x, col, m, pbeg, pend);
+			if (valid) {
 				double v = 0;
-				double x = h_val[h];
-				PAT_FIX(x, col);
 				ok = emit_value(ep, a_scale, col, x, &v);
 				h_key[h] = -1;
 				h_val[h] = ok ? v : 0.0;
@@ -1937,7 +1973,13 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 
 	const unsigned tid = threadIdx.x, lane = lane_id();
 	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
-	for (int q = tid; q < W + 64; q += NT) acc[q] = 0.0;
+	// EXACT_PATTERN: a clean slot holds -0.0.  No sum of products is -0.0 (x + -x = +0, and a product is never a zero: zeros
+	// are dropped at consolidation), -0.0 + p = p exactly, and -0.0 is "not emitted" like +0 -- so the scan-out can tell a slot
+	// no product touched from one whose terms cancelled, and re-evaluates only the latter.  (With +0 as the clean value every
+	// EMPTY slot of a cell with products of both signs was re-evaluated from the operands: 4.8 s instead of 11 ms on a
+	// scale-18 R-MAT with random signs.)
+	const double CLEAN = (PAT && MODE != MODE_COUNT) ? -0.0 : 0.0;
+	for (int q = tid; q < W + 64; q += NT) acc[q] = CLEAN;
 	for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
 	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;    // uniform: the emitted value is the sum itself
 	const unsigned long long laneK = (unsigned long long)lane * 0x9E3779B97F4A7C15ull;
@@ -2203,9 +2245,12 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		for (int gi = 0; gi < GPW; ++gi) {
 			int grp = wv * GPW + gi;
 			double x = acc[grp * 64 + lane];
-			acc[grp * 64 + lane] = 0.0;
+			acc[grp * 64 + lane] = CLEAN;
 			bool ok;
-			if (MODE != MODE_COUNT && PAT) { if (!(fabs(x) > pthr)) x = ordered_sum(m, pbeg, pend, (int32_t)(wbase + grp * 64 + lane)); }
+			if (MODE != MODE_COUNT && PAT) {
+				const bool touched = __double_as_longlong(x) != (long long)0x8000000000000000ull;
+				x = pat_fix_wave(touched && !(fabs(x) > pthr), x, (int32_t)(wbase + grp * 64 + lane), m, pbeg, pend);
+			}
 			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, (int32_t)(wbase + grp * 64 + lane));
 			else if (plain) ok = x != 0;
 			else ok = emit_value(ep, a_scale, (int32_t)(wbase + grp * 64 + lane), x, &x);
@@ -2624,7 +2669,7 @@ constexpr int BM_WORDS = BM_WORDS_V;      // bitmap words: 2048 = 131072 columns
 constexpr int BM_MAXOUT = BM_MAXOUT_V;   // distinct columns of a cell (<= its products)
 constexpr int BM_ITEMS = 8192;           // items per tile
 
-template <int MODE>
+template <int MODE, bool PAT>
 __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32_t ntile, const TCell *tcells, RowMeta m,
 	const uint32_t *bwin, uint32_t nwin1, uint32_t narrow, EmitParams ep, SinkParams sk)
 {
@@ -2639,6 +2684,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 	__shared__ TileX<NT, NWORD> X;
 	__shared__ uint32_t s_wtot[2][NW];
 	__shared__ uint32_t s_wbase[NW];
+	__shared__ PatCell s_pat;                                   // EXACT_PATTERN: sum of |products| and sign mix of the current cell
 	__shared__ uint32_t s_scan[NW + 1];
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
@@ -2650,6 +2696,8 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 	for (int q = tid; q < NWORD; q += NT) X.bmask[q] = 0ull;
 	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;
 	unsigned long long d_cnt = 0, d_hash = 0; double d_sum = 0;
+	PatAcc pat; pat_init(pat);
+	if (PAT && tid == 0) pat_reset(&s_pat);
 	uint32_t flip = 0, sflip = 0;
 	const char *bbase = reinterpret_cast<const char *>(m.btup);
 #ifdef SPSAMD_STAMPS
@@ -2761,14 +2809,21 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					if ((uint32_t)u < nv) {
 						const uint32_t rel = piece.w[3 * u] - colbase;
 						krel[st][u] = rel;
-						if constexpr (MODE != MODE_COUNT) kval[st][u] = av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
+						if constexpr (MODE != MODE_COUNT) {
+							kval[st][u] = av * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
+							if (PAT) pat_note(pat, kval[st][u]);
+						}
 						atomicOr(reinterpret_cast<uint32_t *>(bm) + (rel >> 5), 1u << (rel & 31u));      // (32-bit halves: half the bank traffic of a 64-bit or)
 					}
 				}
 			}
+			if (PAT && MODE != MODE_COUNT) pat_publish(pat, &s_pat);     // (complete at the barrier)
 			STAMP(2);
 			lds_barrier();                                          // the bitmap is complete
 			STAMP(3);
+			// EXACT_PATTERN: every thread takes the cell's bound now; the record is reset after the next barrier (all have
+			// read it) and long before the next cell's waves add to it
+			const double pthr = (PAT && MODE != MODE_COUNT) ? pat_threshold(&s_pat, tile.end - tile.beg) : -1.0;
 			// ---- 2. rank prefix of the bitmap words: thread t owns words [WPT t, WPT t + WPT); bpre holds the prefix INSIDE
 			// the wave's 64 WPT words, the waves' bases go to s_wbase after the barrier (every wave computes and writes the
 			// same eight values and reads back its own writes: no barrier needed for them)
@@ -2802,6 +2857,7 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 			STAMP(4);
 			lds_barrier();
 			STAMP(5);
+			if (PAT && MODE != MODE_COUNT && tid == 0) pat_reset(&s_pat);
 			uint32_t distinct;
 			{
 				const uint32_t t = lane < (unsigned)NW ? s_wtot[sflip][lane] : 0u;
@@ -2860,16 +2916,28 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, col, v, &v);
 					if (ok) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
 				};
-				for (uint32_t i = tid; i < distinct; i += 2 * NT) {     // two ranks per trip: their LDS reads overlap
-					const uint32_t j = i + NT;
-					const bool two = j < distinct;
-					const uint32_t jj = two ? j : i;
-					const uint32_t rel0 = colof[i], rel1 = colof[jj];
-					const double v0 = acc[i], v1 = acc[jj];
-					acc[i] = 0.0;
-					if (two) acc[j] = 0.0;
-					note(rel0, v0);
-					if (two) note(rel1, v1);
+				if constexpr (!PAT) {
+					for (uint32_t i = tid; i < distinct; i += 2 * NT) {     // two ranks per trip: their LDS reads overlap
+						const uint32_t j = i + NT;
+						const bool two = j < distinct;
+						const uint32_t jj = two ? j : i;
+						const uint32_t rel0 = colof[i], rel1 = colof[jj];
+						const double v0 = acc[i], v1 = acc[jj];
+						acc[i] = 0.0;
+						if (two) acc[j] = 0.0;
+						note(rel0, v0);
+						if (two) note(rel1, v1);
+					}
+				} else {
+					for (uint32_t base = 0; base < distinct; base += NT) {  // uniform trips: pat_fix_wave wants whole waves
+						const uint32_t i = base + tid;
+						const bool valid = i < distinct;
+						const uint32_t rel = valid ? colof[i] : 0u;
+						double v = valid ? acc[i] : 0.0;
+						if (valid) acc[i] = 0.0;
+						v = pat_fix_wave(valid && !(fabs(v) > pthr), v, (int32_t)(colbase + rel), m, tile.beg, tile.end);
+						if (valid) note(rel, v);
+					}
 				}
 				d_cnt += cnt; d_sum += vs;
 				if (sk.row_nnz) {
@@ -2898,9 +2966,17 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 				// COO: rank order IS column order.  Usually every column of the cell yields a tuple and its place is its
 				// rank; only where a sum cancelled to exactly 0 (or scalek drops a column) the survivors are compacted by scans
 				uint32_t nbad = 0;
-				for (uint32_t i = tid; i < distinct; i += NT) {
-					double v = acc[i];
-					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + colof[i]), v, &v);
+				for (uint32_t base = 0; base < distinct; base += NT) {      // (uniform trips)
+					const uint32_t i = base + tid;
+					const bool valid = i < distinct;
+					const uint32_t rel = valid ? colof[i] : 0u;
+					double v = valid ? acc[i] : 1.0;
+					if (PAT) {
+						const bool need = valid && !(fabs(v) > pthr);
+						v = pat_fix_wave(need, v, (int32_t)(colbase + rel), m, tile.beg, tile.end);
+						if (need) acc[i] = v;                               // (kept: the store loop below reads it)
+					}
+					const bool ok = !valid || (plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v));
 					if (!ok) ++nbad;
 				}
 				const int any_bad = __syncthreads_or((int)nbad);
@@ -3287,7 +3363,7 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 		SinkParams sk2 = sk;
 		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
 		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
-		k_bm_tiles<MODE><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
+		k_bm_tiles<MODE, false><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk2);
 		{
 			std::vector<unsigned long long> h((size_t)grid * 12);
 			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -3300,7 +3376,8 @@ static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, 
 			fprintf(stderr, "\n");
 		}
 #else
-		k_bm_tiles<MODE><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+		if (ep.pattern) k_bm_tiles<MODE, true><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
+		else k_bm_tiles<MODE, false><<<dim3(grid), dim3(BM_NT), 0, c->stream>>>(hv.tb.tiles, hv.ntile, hv.tb.tcells, m, hv.bwin, hv.nwin1, narrow, ep, sk);
 #endif
 		SPS_LAUNCH_CHECK();
 	} else if (hv.ntile && hv.tiles2 == 2) {
@@ -3489,9 +3566,9 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
 	hv.tb.enabled = !c->tune.no_tiles;
 	// Tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles v2.
-	// ORDERED runs on the first generation, EXACT_PATTERN on the hash tiles v2 (the variants that exist); otherwise the
-	// choice is made per call below, by counting the cells either scheme would cut.
-	const bool free_choice = !ordered && !pattern && c->tune.tiles_v1 == 0;
+	// ORDERED runs on the first generation (the variant that exists), EXACT_PATTERN on the bitmap tiles or the hash tiles v2;
+	// otherwise the choice is made per call below, by counting the cells either scheme would cut.
+	const bool free_choice = !ordered && c->tune.tiles_v1 == 0;
 	const bool user_dense_min = c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP;
 	auto set_scheme = [&](int scheme) {
 		hv.tiles2 = scheme;
@@ -3500,7 +3577,7 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 		hv.tb.pb = scheme != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
 		hv.span_cap = scheme == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
 	};
-	set_scheme(ordered ? 1 : pattern ? 2 : (c->tune.tiles_v1 == 1 ? 1 : (c->tune.tiles_v1 == 2 ? 2 : 0)));
+	set_scheme(ordered ? 1 : (c->tune.tiles_v1 == 1 ? (pattern ? 2 : 1) : (c->tune.tiles_v1 == 2 ? 2 : 0)));
 	// Rows too long for a tile: a hash-class cell of theirs reads B in row-major pieces of 4.4 tuples on average -- 6x the
 	// algorithmic bytes from HBM at line granularity (FETCH_SIZE of k_hash<3072>: 14.8 GB for 2.5 GB) -- while the dense kernel
 	// reads the window-major copy.  Their windows go to k_dense from LONG_DENSE_MIN products on.  R-MAT A*A, ms per step:
