@@ -700,6 +700,11 @@ def test_exact_pattern_mode_mixed_signs(ctx):
     key = lambda r: r[0].astype(np.int64) * a[3][1] + r[1]
     pos = np.searchsorted(key(bound), key(want2))
     assert np.all(np.abs(got2[2] - want2[2]) <= 1e-12 * bound[2][pos])
+    # ... at a sane price: a dense cell with both signs once re-evaluated every EMPTY slot of its window from the
+    # operands (170x the default time on this size); only touched slots whose sum the bound cannot decide are candidates
+    plain2 = _dev(ctx, A2, A2)
+    got2 = _dev(ctx, A2, A2, flags=capi.SINK_EXACT_PATTERN)   # (second call: no workspace growth in the time)
+    assert got2[3].ms_total <= 5.0 * plain2[3].ms_total + 2.0, (got2[3].ms_total, plain2[3].ms_total)
 
 
 def test_poisson_exact(ctx):
