@@ -87,6 +87,35 @@ inline Context &default_context()
 	return *ctx;
 }
 
+// ---- cursor over a COO container: the surface of the reference's CooIterator (array.hpp:70-115) -- index(),
+// index(k), val(), offset(), set_index(), random-access stepping, comparison by position
+template <class ArrayT, class IndexRefT, class ValRefT>
+class CooCursor {
+	ArrayT *arr_;
+	int at_;
+public:
+	static const int rank = ArrayT::rank;
+	typedef typename ArrayT::indices_type indices_type;
+	typedef indices_type value_type;
+	typedef typename ArrayT::index_type index_type;
+	typedef typename ArrayT::val_type val_type;
+	CooCursor(ArrayT *arr, int at) : arr_(arr), at_(at) {}
+	indices_type operator[](int n) const { return arr_->index(at_ + n); }
+	indices_type index() const { return arr_->index(at_); }
+	indices_type operator*() const { return arr_->index(at_); }
+	CooCursor &operator+=(int n) { at_ += n; return *this; }
+	CooCursor &operator-=(int n) { at_ -= n; return *this; }
+	CooCursor &operator++() { ++at_; return *this; }
+	CooCursor &operator--() { --at_; return *this; }
+	CooCursor operator+(int n) const { return CooCursor(arr_, at_ + n); }
+	bool operator==(CooCursor const &o) const { return at_ == o.at_; }
+	bool operator!=(CooCursor const &o) const { return at_ != o.at_; }
+	int offset() const { return at_; }
+	IndexRefT index(int k) const { return arr_->index(k, (size_t)at_); }
+	void set_index(indices_type const &idx) const { arr_->set_index(at_, idx); }
+	ValRefT val() const { return arr_->val((size_t)at_); }
+};
+
 // ---- host container with VectorCooArray's surface (VectorCooArray.hpp:8-158)
 template <class IndexT, class ValT, int RANK>
 class VectorCooArray {
@@ -116,7 +145,26 @@ public:
 		for (int k = 0; k < RANK; ++k) r[k] = index(k, (size_t)ix);
 		return r;
 	}
+	// VectorCooArray.hpp:60-67
+	std::vector<IndexT> index_vec(int ix) const
+	{
+		std::vector<IndexT> r;
+		for (int k = 0; k < RANK; ++k) r.push_back(index(k, (size_t)ix));
+		return r;
+	}
+	void set_index(int ix, std::array<IndexT, RANK> const &idx) { for (int k = 0; k < RANK; ++k) index(k, (size_t)ix) = idx[k]; }
 	size_t size() const { return val_vec.size(); }
+
+	// VectorCooArray.hpp:88-104: iterator = cursor at a tuple position; begin(ix) / end(ix) offset from the ends
+	typedef CooCursor<VectorCooArray, IndexT &, ValT &> iterator;
+	typedef CooCursor<const VectorCooArray, IndexT const &, ValT const &> const_iterator;
+	iterator begin(int ix = 0) { return iterator(this, ix); }
+	iterator end(int ix = 0) { return iterator(this, (int)size() + ix); }
+	const_iterator cbegin(int ix = 0) const { return const_iterator(this, ix); }
+	const_iterator cend(int ix = 0) const { return const_iterator(this, (int)size() + ix); }
+	const_iterator begin(int ix = 0) const { return const_iterator(this, ix); }
+	const_iterator end(int ix = 0) const { return const_iterator(this, (int)size() - ix); }      // (sic: VectorCooArray.hpp:104 subtracts)
+
 	void clear()
 	{
 		for (int k = 0; k < RANK; ++k) index_vecs[k].clear();

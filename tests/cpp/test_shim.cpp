@@ -31,6 +31,32 @@ static std::vector<double> to_dense(Mat const &A)
 	return d;
 }
 
+// tests/test_array.cpp:80-105 (iterator) and :236-242 (iterating a consolidated matrix against its dense form)
+static void test_iterators()
+{
+	Mat arr2({4, 5});
+	arr2.add({1, 3}, 5.);
+	arr2.add({2, 4}, 3.);
+	arr2.add({1, 2}, 3.);
+	auto ii(arr2.begin());
+	CHECK(ii != arr2.end());
+	CHECK(ii.index(0) == 1 && ii.index(1) == 3 && ii.val() == 5.);
+	ii.val() = 17.;
+	CHECK(ii.val() == 17. && arr2.val(0) == 17.);
+	++ii; ++ii;
+	CHECK(ii.offset() == 2 && ii.index(0) == 1 && ii.index(1) == 2 && ii.val() == 3.);
+	CHECK((*ii)[0] == 1 && ii.index()[1] == 2 && ii[-1][0] == 2);
+	ii.set_index({3, 0});
+	CHECK(arr2.index(0, 2) == 3 && arr2.index(1, 2) == 0 && arr2.index_vec(2)[0] == 3);
+	++ii;
+	CHECK(ii == arr2.end() && (arr2.begin() + 3) == arr2.end() && arr2.end(-1).offset() == 2);
+	Mat const &carr(arr2);
+	size_t n = 0;
+	std::vector<double> dense(to_dense(arr2));
+	for (auto ci(carr.begin()); ci != carr.end(); ++ci, ++n) CHECK(dense[ci.index(0) * arr2.shape[1] + ci.index(1)] == ci.val());
+	CHECK(n == 3 && carr.cbegin(1).offset() == 1);
+}
+
 // tests/test_multiply_sparse.cpp:45-78 (the #if 0 known answer)
 static void test_known_answer()
 {
@@ -263,8 +289,10 @@ int main(int argc, char **argv)
 		int rc = spsamd_ctx_create(&c, -1, nullptr);
 		std::printf("spsamd_ctx_create -> %d (%s)\n", rc, rc == SPSAMD_ENODEVICE ? "no device: fails loudly, no fallback" : "device present");
 		if (c) spsamd_ctx_destroy(c);
-		return (rc == 0 || rc == SPSAMD_ENODEVICE) ? 0 : 1;
+		test_iterators();                                           // host-only: the container's iterator surface
+		return ((rc == 0 || rc == SPSAMD_ENODEVICE) && !failures) ? 0 : 1;
 	}
+	test_iterators();
 	test_known_answer();
 	long ntuples = 0;
 	for (int seed = 1; seed < 1000; ++seed) test_random_MM_multiply(5, seed, &ntuples);
