@@ -2917,14 +2917,15 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 					if (ok) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
 				};
 				if constexpr (!PAT) {
+					unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
 					for (uint32_t i = tid; i < distinct; i += 2 * NT) {     // two ranks per trip: their LDS reads overlap
 						const uint32_t j = i + NT;
 						const bool two = j < distinct;
-						const uint32_t jj = two ? j : i;
+						const uint32_t jj = two ? j : i;                        // (i again: the second exchange then reads the 0 the first left)
 						const uint32_t rel0 = colof[i], rel1 = colof[jj];
-						const double v0 = acc[i], v1 = acc[jj];
-						acc[i] = 0.0;
-						if (two) acc[j] = 0.0;
+						// read and clean in one LDS operation each
+						const double v0 = __longlong_as_double((long long)atomicExch(&acc64[i], 0ull));
+						const double v1 = __longlong_as_double((long long)atomicExch(&acc64[jj], 0ull));
 						note(rel0, v0);
 						if (two) note(rel1, v1);
 					}
