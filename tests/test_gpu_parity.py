@@ -563,6 +563,55 @@ def test_every_cell_scheme_against_the_oracle(ctx, knobs):
         assert res.products_tiles > 0
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_random_knobs_signs_and_flags(ctx, seed):
+    """Differential stress of the heavy-row kernels: R-MAT operands of random scale (A*A and A*B), random signs, a random
+    subset of the tuning knobs, the default and the EXACT_PATTERN flag, 'T' flags and C != 1 -- every draw against the
+    row-wise oracle (index set exact, values to 1e-12 of the sum of |terms|)."""
+    from spsparse_amd import capi
+    rng = np.random.default_rng(1000 + seed)
+    scale = int(rng.choice([12, 13, 14, 15]))
+    a = wl.rmat(scale, seed=20 + seed)
+    va = a[2] * rng.choice([-1.0, 1.0], size=a[2].size) if seed % 2 else a[2]
+    A = orc.Mat(a[0], a[1], va, a[3])
+    if seed % 3 == 0:
+        B = A
+    else:
+        b = wl.rmat(scale, seed=40 + seed)
+        B = orc.Mat(b[0], b[1], b[2] * rng.choice([-1.0, 1.0], size=b[2].size), b[3])
+    pool = {"tiles_v1": [1, 2, 3], "dense_min": [256, 1024, 2048, 4096], "long_dense_min": [64, 512, 4096], "cell_cap": [512, 1024, 4096],
+            "direct_min": [512, 1536], "no_wmajor": [1], "window": [16384], "no_tiles": [1], "long_cap": [4096], "emit_path": [1, 2]}
+    knobs = {k: int(rng.choice(v)) for k, v in pool.items() if rng.uniform() < 0.3}
+    kw = dict(tA=str(rng.choice([".", "T"])), tB=str(rng.choice([".", "T"])), C_=float(rng.choice([1.0, -0.5])))
+    flags = capi.SINK_EXACT_PATTERN if seed % 2 else 0
+    want = orc.multiply(A, B, rowwise=True, nthreads=8, **kw)
+    absA, absB = orc.Mat(A.idx0, A.idx1, np.abs(A.val), A.shape), orc.Mat(B.idx0, B.idx1, np.abs(B.val), B.shape)
+    bound = orc.multiply(absA, absB, rowwise=True, nthreads=8, tA=kw["tA"], tB=kw["tB"], C_=abs(kw["C_"]))
+    for k, v in knobs.items():
+        ctx.set_tuning(k, v)
+    try:
+        got = _dev(ctx, A, B, flags=flags, **kw)
+        _, _, _, d = _dev(ctx, A, B, flags=flags, sink=capi.SINK_DIGEST, **kw)
+    finally:
+        for k in knobs:
+            ctx.set_tuning(k, 0)
+    ncol = int(want[3][1]) if len(want) > 3 else int(max(A.shape[1], B.shape[1], A.shape[0], B.shape[0]))
+    key = lambda r: r[0].astype(np.int64) * (1 << 32) + r[1]
+    if flags:
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), knobs
+        pos = np.searchsorted(key(bound), key(want))
+        assert np.all(np.abs(got[2] - want[2]) <= 1e-12 * bound[2][pos]), knobs
+        assert d.nnz == len(want[0])
+    else:
+        # default mode: a sum that cancels to rounding may differ in its zero test; with random real values none does
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), knobs
+        pos = np.searchsorted(key(bound), key(want))
+        assert np.all(np.abs(got[2] - want[2]) <= 1e-12 * bound[2][pos]), knobs
+        cnt, s_, h = orc.digest(*want[:3])
+        assert d.nnz == cnt and d.hash == h, knobs
+    assert got[3].rows_heavy > 0
+
+
 @pytest.mark.parametrize("tA,tB", [(".", "."), ("T", "."), (".", "T"), ("T", "T")])
 def test_heavy_rows_with_scales_and_flags(ctx, tA, tB):
     """Scale vectors (absent indices, zero scales), C != 1 and 'T' flags on an R-MAT product whose rows
