@@ -175,18 +175,28 @@ __device__ __forceinline__ void pat_note(PatAcc &a, double p)
 	const uint32_t hi = (uint32_t)__double2hiint(p);
 	a.sor |= hi; a.sand &= hi;
 }
-// every wave adds its lanes' notes to the cell's record (call before the barrier that ends the accumulation)
+// every wave adds its lanes' notes to the cell's record (call before the barrier that ends the accumulation).  The wave
+// reduction runs on DPP (row shifts and broadcasts: VALU only; lane 63 ends up with the total) -- with __shfl_xor it was 24
+// ds_bpermute per wave and cell, in kernels whose LDS pipe is the busy one.
 __device__ __forceinline__ void pat_publish(PatAcc &a, PatCell *cell)
 {
 	double sa = a.sabs;
 	uint32_t so = a.sor, sn = a.sand;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-		sa += __shfl_xor(sa, d, 64);
-		so |= (uint32_t)__shfl_xor((int)so, d, 64);
-		sn &= (uint32_t)__shfl_xor((int)sn, d, 64);
-	}
-	if (lane_id() == 0) { atomicAdd(&cell->sabs, sa); atomicOr(&cell->sor, so); atomicAnd(&cell->sand, sn); }
+#define PAT_DPP_STEP(ctrl, rows) do { \
+		const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(sa), ctrl, rows, 0xF, true); \
+		const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(sa), ctrl, rows, 0xF, true); \
+		sa += __hiloint2double(hi_, lo_); \
+		so |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)so, ctrl, rows, 0xF, true); \
+		sn &= (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sn, ctrl, rows, 0xF, false); \
+	} while (0)
+	PAT_DPP_STEP(0x111, 0xF);       // row_shr:1
+	PAT_DPP_STEP(0x112, 0xF);       // row_shr:2
+	PAT_DPP_STEP(0x114, 0xF);       // row_shr:4
+	PAT_DPP_STEP(0x118, 0xF);       // row_shr:8
+	PAT_DPP_STEP(0x142, 0xA);       // row_bcast:15 -> rows 1 and 3
+	PAT_DPP_STEP(0x143, 0xC);       // row_bcast:31 -> rows 2 and 3
+#undef PAT_DPP_STEP
+	if (lane_id() == 63) { atomicAdd(&cell->sabs, sa); atomicOr(&cell->sor, so); atomicAnd(&cell->sand, sn); }
 	pat_init(a);
 }
 __device__ __forceinline__ void pat_reset(PatCell *cell) { cell->sabs = 0.0; cell->sor = 0u; cell->sand = 0xFFFFFFFFu; }
