@@ -412,8 +412,8 @@ def main():
 
 
 def roofline_of(args, world, results, scale_is_cfg2):
-    """Dominant kernel of rank 0 = the numeric kernel with the largest duration, timed with HIP events on the
-    library's stream in every step.  Algorithmic bytes of one launch = 12 B per scalar product it
+    """Dominant kernel of rank 0 = the numeric kernel with the largest duration (ties within 3 %: the one with more
+    algorithmic bytes), timed with HIP events on the library's stream in every step.  Algorithmic bytes of one launch = 12 B per scalar product it
     processes + 16 B per A tuple of its rows."""
     res = results[-1]
 
@@ -426,13 +426,17 @@ def roofline_of(args, world, results, scale_is_cfg2):
         return res.tuples_heavy * p / t_heavy
     kernels = [
         ("k_dense", avg(lambda r: r.ms_dense), res.products_dense, tup(res.products_dense)),
-        ("k_hash_tiles", avg(lambda r: r.ms_tiles), res.products_tiles, tup(res.products_tiles)),
+        ("k_bm_tiles|k_hash_tiles2", avg(lambda r: r.ms_tiles), res.products_tiles, tup(res.products_tiles)),
         ("k_direct_tiles", avg(lambda r: r.ms_direct), res.products_direct, tup(res.products_direct)),
         ("k_hash(window cells)", avg(lambda r: r.ms_heavy - r.ms_dense - r.ms_tiles - r.ms_direct), p_win, tup(p_win)),
         ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
         ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
     ]
-    name, ms_kernel, k_prod, k_tup = max(kernels, key=lambda k: k[1])
+    # dominant = longest; kernels within 3 % of the longest count as tied (k_dense and the tile kernel take 32.5 and 32.2 ms
+    # of a cfg2 step) and the tie goes to the one that moves more algorithmic bytes, so that the headline figure does not
+    # flip between two kernels with the run-to-run noise.  all_kernels lists every kernel either way.
+    t_max = max(k[1] for k in kernels)
+    name, ms_kernel, k_prod, k_tup = max((k for k in kernels if k[1] >= 0.97 * t_max), key=lambda k: 16 * k[3] + 12 * k[2])
     alg_bytes = int(16 * k_tup + 12 * k_prod)
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
     # HBM-side bytes per launch: bench.py cannot run the profiler on itself, so this is the figure of the

@@ -43,7 +43,7 @@ def group(name):
     if "k_dense" in name:
         return "k_dense"
     if "k_hash_tiles" in name or "k_bm_tiles" in name:
-        return "k_hash_tiles"
+        return "k_bm_tiles|k_hash_tiles2"
     if "k_direct_tiles" in name:
         return "k_direct_tiles"
     if "k_hash<" in name and "true" in name.split(",")[3]:
