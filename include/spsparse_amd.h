@@ -25,12 +25,13 @@
  *   - indices int32, fewer than 2^31 tuples per operand (like the reference's int positions,
  *     algorithm.hpp:419); one output row may hold at most 2^32-1 scalar products.
  *   - rows with more than 4096 scalar products ("heavy" rows) are cut along column windows of 8192
- *     columns (16384 above 2^21 columns): at most 2048 windows, i.e. op(B) may have at most 2^25 columns
- *     when the product has a heavy row.  Products whose rows all stay at or below 4096 scalar products
- *     have no column limit below 2^31.
- *   - the heavy-row path keeps two dense indices of rows(op(B)) x (windows + 1) 32-bit positions in the
- *     workspace (0.5 GB each for a 2^20-square matrix, 17 GB each at 2^23): SPSAMD_ENOMEM if the device
- *     cannot hold them.
+ *     columns (16384 above 2^21 columns), at most 2048 of them.  A product with a heavy row and more than
+ *     2^25 columns in op(B) is multiplied by column blocks of op(B), 2^25 columns at a time (same result,
+ *     slower: every block repeats the work on A and a COO result is assembled by one more pass).
+ *   - the heavy-row path keeps dense indices of rows(op(B)) x windows entries in the workspace (12 bytes per
+ *     row and window: 1.6 GB for a 2^20-square matrix, 50 GB at 2^23).  Where they would not fit the device the
+ *     product also goes by column blocks, narrow enough for them to fit; SPSAMD_ENOMEM only if one window's
+ *     share does not.
  */
 #ifndef SPSPARSE_AMD_H
 #define SPSPARSE_AMD_H
@@ -179,6 +180,8 @@ const char *spsamd_version(void);
  *   no_tiles, no_wmajor, xcd          1: no tiles | no window-major copy of B | XCD-partitioned cell lists
  *   emit_path       1 | 2             COO order of a hash cell: LDS radix sort | bitonic network (default: by cell width)
  *   light_path      1                 binned light kernels even where every row is light
+ *   index_budget_mb > 0               cap of the heavy rows' window indices (default: 80 % of the free device memory);
+ *                                     beyond it the product goes by column blocks of op(B)
  * The environment variables of the same purpose (SPSAMD_W ...) are read once, inside spsamd_ctx_create; nothing reads
  * the environment later.  Unknown names: SPSAMD_EINVAL. */
 int spsamd_ctx_set_tuning(spsamd_ctx *ctx, const char *name, long value);

@@ -37,6 +37,14 @@ void *Arena::alloc(size_t bytes)
 	return s.p;
 }
 
+void Arena::rewind(const Mark &m)
+{
+	if (call_used > high_water) high_water = call_used;             // the peak counts, not what is live afterwards
+	for (size_t q = m.nslabs; q < slabs.size(); ++q) slabs[q].used = 0;
+	if (m.nslabs && m.nslabs <= slabs.size() && m.nslabs == slabs.size()) slabs[m.nslabs - 1].used = m.used;
+	call_used = m.call_used;
+}
+
 void Arena::reset()
 {
 	if (call_used > high_water) high_water = call_used;

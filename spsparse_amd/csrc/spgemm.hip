@@ -3326,6 +3326,11 @@ static void launch_mid(spsamd_ctx *c, const Bins &b, const MidCells &mc, const R
 	launch_hash<8192, 512, MODE, false>(c, mc.cells[2], b.count[7], nullptr, m, nullptr, 0, ep, sk);   // 115 KB of LDS: one workgroup per CU, so make it 8 waves
 }
 
+// Thrown by heavy_prepare: op(B) has more column windows than the heavy-row path indexes, or its window indices would not
+// fit the device -- spgemm() then multiplies by column blocks of `width` columns (spgemm_column_blocks).
+struct TooWide { uint64_t width; };
+constexpr uint64_t COLBLK = (uint64_t)2048 << 14;                   // 2048 windows of 16384 columns: 2^25
+
 struct Heavy {
 	uint32_t n = 0;                  // heavy rows
 	uint32_t *rows = nullptr;
@@ -3544,9 +3549,31 @@ static void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowM
 	if (c->tune.window == 8192 || c->tune.window == 16384) hv.W = c->tune.window;
 	const uint32_t wshift = hv.W == 8192 ? 13 : 14;
 	hv.nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
-	if (hv.nwin > (uint32_t)WH_MAXW) throw Error{SPSAMD_EINVAL, "too many column windows (ncol > 2^25) for the heavy-row path"};
+	if (hv.nwin > (uint32_t)WH_MAXW) throw TooWide{COLBLK};         // spgemm() then multiplies by column blocks of B
 	hv.nwin1 = hv.nwin + 1;
 	const uint64_t nrowb = B.nrow + extra;
+	{
+		// The window indices (bwin, its 16-bit counts, the window-major pointer with its counts, the heavy rows' histograms)
+		// grow with rows(B) x windows: 12 bytes per B row and window.  Where they would not fit what the device has left
+		// (or the cap a test sets), the product goes by column blocks narrow enough for them to fit.
+		const uint64_t per_window = nrowb * 12u + (uint64_t)hv.n * 4u;
+		uint64_t budget;
+		const uint64_t room = c->arena.slabs.empty() ? 0 : c->arena.slabs.back().cap - c->arena.slabs.back().used;
+		if (c->tune.index_budget_mb > 0) budget = (uint64_t)c->tune.index_budget_mb << 20;
+		else if (per_window * (hv.nwin + 1ull) <= room) budget = room;  // (the steady state: the workspace of an earlier call holds them)
+		else {
+			size_t freeb = 0, totalb = 0;
+			SPS_HIP(hipMemGetInfo(&freeb, &totalb));
+			budget = (uint64_t)((double)(freeb + room) * 0.8);
+		}
+		if (per_window * (hv.nwin + 1ull) > budget && hv.nwin > 1) {
+			uint64_t fit = budget / per_window;                         // windows per block that fit
+			if (fit < 2) throw Error{SPSAMD_ENOMEM, "the window index of one column window of op(B) does not fit the device"};
+			uint64_t w2 = 1;
+			while (w2 * 2 <= fit - 1) w2 *= 2;
+			throw TooWide{w2 << wshift};
+		}
+	}
 	hv.nrowb = nrowb;
 	hv.nnzb = B.nnz;
 	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
@@ -3717,6 +3744,64 @@ static void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32
 	}
 }
 
+// ---- products with a heavy row and more than 2^25 columns: by column blocks of B -----------------------------
+// The heavy-row kernels index B by column windows and take 2048 of them (2^25 columns at 16384 per window), and their
+// indices hold 12 bytes per row of B and window.  A wider op(B) with a heavy row -- or one whose indices would not fit the
+// device -- is multiplied block by block: B restricted to `colblk` columns at a time (column indices rebased,
+// scalek shifted) goes through the ordinary path into the COO sink, and the blocks' outputs -- each row-major -- are
+// interleaved row by row (a row's tuples of block 0, then of block 1, ...: ascending columns).  The digest sink is fed
+// from the blocks' tuples with their absolute columns.  A fallback for an uncommon shape, not a fast path: every block
+// repeats the work on A, and the COO result is assembled by one extra pass over the output.
+
+__global__ void k_col_flag(const int32_t *col, uint32_t n, uint32_t c0, uint32_t c1, uint8_t *flag)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) { const uint32_t cc = (uint32_t)col[t]; flag[t] = (cc >= c0 && cc < c1) ? 1 : 0; }
+}
+
+__global__ void k_col_compact(const int32_t *row, const int32_t *col, const double *val, const uint8_t *flag, const uint32_t *off, uint32_t n,
+	uint32_t c0, int32_t *orow, int32_t *ocol, double *oval)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n && flag[t]) { const uint32_t o = off[t]; orow[o] = row[t]; ocol[o] = (int32_t)((uint32_t)col[t] - c0); oval[o] = val[t]; }
+}
+
+__global__ void k_block_digest(const int32_t *i, const int32_t *j, const double *v, uint64_t n, uint32_t c0, DigestSlot *slots,
+	long long *row_nnz, double *row_sum)
+{
+	__shared__ unsigned long long s_u64[2 * 4];
+	__shared__ double s_f64[4];
+	unsigned long long cnt = 0, hash = 0; double sum = 0;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t jj = (uint32_t)j[t] + c0;
+		++cnt; hash += mix64((uint32_t)i[t], jj); sum += v[t];
+		if (row_nnz) { atomicAdd((unsigned long long *)&row_nnz[i[t]], 1ull); atomicAdd(&row_sum[i[t]], v[t]); }
+	}
+	digest_flush<256>(slots, cnt, hash, sum, s_u64, s_f64);
+}
+
+__global__ void k_add_col(int32_t *j, uint64_t n, uint32_t c0)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) j[t] = (int32_t)((uint32_t)j[t] + c0);
+}
+
+__global__ void k_row_add_counts(const uint32_t *rp, uint64_t nrow, uint32_t *cnt)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < nrow) cnt[r] += rp[r + 1] - rp[r];
+}
+
+__global__ void k_block_place(const int32_t *i, const int32_t *j, const double *v, uint64_t n, const uint32_t *rp, const int64_t *rowoff,
+	const uint32_t *cur, int32_t *oi, int32_t *oj, double *ov)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const int32_t r = i[t];
+	const int64_t d = rowoff[r] + (int64_t)cur[r] + (int64_t)(t - rp[r]);
+	oi[d] = r; oj[d] = j[t]; ov[d] = v[t];
+}
+
 template <int S, int MODE>
 static void launch_light_direct(spsamd_ctx *c, uint32_t nrow, const uint32_t *aptr, const int32_t *acol, const double *aval,
 	const uint32_t *bptr, const ConMat &B, bool k64, const EmitParams &ep, const SinkParams &sk, unsigned long long *pc)
@@ -3810,7 +3895,7 @@ static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res,
 	res->ms_light = elapsed(c->ev[3], c->ev[4]);
 }
 
-void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
+static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 {
 	hipStream_t st = c->stream;
 	const ConMat &A = a.A, &B = a.B;
@@ -4050,6 +4135,154 @@ void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->ms_numeric = elapsed(c->ev[2], c->ev[7]);
 	res->ms_light = ms_light; res->ms_mid = ms_mid; res->ms_heavy = ms_heavy; res->ms_dense = ms_dense;
 	if (hv.n) { res->ms_tiles = elapsed(c->ev2[0], c->ev2[1]); res->ms_direct = elapsed(c->ev2[1], c->ev2[2]); }    // (COO: of the STORE launches)
+}
+
+static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res, uint64_t colblk)
+{
+	hipStream_t st = c->stream;
+	const ConMat &A = a.A, &B = a.B;
+	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
+	const uint32_t nblk = (uint32_t)((B.ncol + colblk - 1) / colblk);
+	struct BlockOut { int32_t *i = nullptr, *j = nullptr; double *v = nullptr; uint64_t n = 0; };
+	struct Blocks {                                                 // the blocks' COO outputs until they are interleaved
+		std::vector<BlockOut> b;
+		~Blocks() { for (auto &x : b) { (void)hipFree(x.i); (void)hipFree(x.j); (void)hipFree(x.v); } }
+	} blocks;
+	DigestSlot *slots = nullptr;
+	long long *row_nnz = nullptr; double *row_sum = nullptr;
+	if (!coo) {
+		slots = c->arena.get<DigestSlot>(DIGEST_SLOTS + 1);
+		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
+		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) {
+			c->rowstat_n.ensure(A.nrow * sizeof(long long));
+			c->rowstat_s.ensure(A.nrow * sizeof(double));
+			fill_zero(c, c->rowstat_n.p, A.nrow * sizeof(long long));
+			fill_zero(c, c->rowstat_s.p, A.nrow * sizeof(double));
+			row_nnz = (long long *)c->rowstat_n.p; row_sum = (double *)c->rowstat_s.p;
+		}
+	}
+	spsamd_result acc{};
+	for (uint32_t s = 0; s < nblk; ++s) {
+		const uint64_t c0 = (uint64_t)s * colblk, c1 = std::min<uint64_t>(B.ncol, c0 + colblk);
+		const Arena::Mark mk = c->arena.mark();
+		// B restricted to columns [c0, c1), rebased; the tuples keep their (row, column) order
+		uint8_t *flag = c->arena.get<uint8_t>(B.nnz);
+		uint32_t *off = c->arena.get<uint32_t>((size_t)B.nnz + 1);
+		k_col_flag<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.nnz, (uint32_t)c0, (uint32_t)c1, flag);
+		SPS_LAUNCH_CHECK();
+		scan_exclusive_u8_u32(c, flag, off, B.nnz);
+		const uint32_t nb = read_back(c, off + B.nnz);
+		if (nb) {
+			MultiplyArgs as = a;
+			as.B.row = c->arena.get<int32_t>(nb); as.B.col = c->arena.get<int32_t>(nb); as.B.val = c->arena.get<double>(nb);
+			as.B.nnz = nb; as.B.nrow = B.nrow; as.B.ncol = c1 - c0;
+			k_col_compact<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, flag, off, B.nnz, (uint32_t)c0, as.B.row, as.B.col, as.B.val);
+			SPS_LAUNCH_CHECK();
+			if (as.sk.present) { as.sk.pos += c0; as.sk.dim = c1 - c0; }
+			as.sink_kind = SPSAMD_SINK_COO;
+			as.sink_flags = a.sink_flags & (SPSAMD_SINK_ORDERED | SPSAMD_SINK_EXACT_PATTERN);
+			spsamd_result rs{};
+			try { spgemm_once(c, as, &rs); }
+			catch (const TooWide &) { throw Error{SPSAMD_ENOMEM, "the window indices of a column block of op(B) do not fit the device"}; }
+			acc.products += rs.products; acc.products_light += rs.products_light; acc.products_mid += rs.products_mid;
+			acc.products_heavy += rs.products_heavy; acc.products_dense += rs.products_dense; acc.products_tiles += rs.products_tiles;
+			acc.cells_hash += rs.cells_hash; acc.cells_dense += rs.cells_dense; acc.window = std::max(acc.window, rs.window);
+			acc.rows_light = std::max(acc.rows_light, rs.rows_light); acc.rows_mid = std::max(acc.rows_mid, rs.rows_mid);
+			acc.rows_heavy = std::max(acc.rows_heavy, rs.rows_heavy);
+			acc.ms_symbolic += rs.ms_symbolic; acc.ms_numeric += rs.ms_numeric; acc.ms_light += rs.ms_light; acc.ms_mid += rs.ms_mid;
+			acc.ms_heavy += rs.ms_heavy; acc.ms_dense += rs.ms_dense; acc.ms_tiles += rs.ms_tiles;
+			if (rs.nnz) {
+				if (!coo) {
+					k_block_digest<<<dim3(std::min<unsigned>(grid_for((size_t)rs.nnz), 4096u)), dim3(256), 0, st>>>(rs.idx0, rs.idx1, rs.val, rs.nnz, (uint32_t)c0, slots, row_nnz, row_sum);
+					SPS_LAUNCH_CHECK();
+				} else {
+					BlockOut bo;
+					bo.n = rs.nnz;
+					if (hipMalloc((void **)&bo.i, rs.nnz * sizeof(int32_t)) != hipSuccess || hipMalloc((void **)&bo.j, rs.nnz * sizeof(int32_t)) != hipSuccess ||
+						hipMalloc((void **)&bo.v, rs.nnz * sizeof(double)) != hipSuccess) {
+						(void)hipGetLastError();
+						(void)hipFree(bo.i); (void)hipFree(bo.j); (void)hipFree(bo.v);
+						throw Error{SPSAMD_ENOMEM, "hipMalloc of a column block's output failed"};
+					}
+					blocks.b.push_back(bo);
+					SPS_HIP(hipMemcpyAsync(bo.i, rs.idx0, rs.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+					SPS_HIP(hipMemcpyAsync(bo.j, rs.idx1, rs.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+					SPS_HIP(hipMemcpyAsync(bo.v, rs.val, rs.nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+					k_add_col<<<dim3(grid_for((size_t)rs.nnz)), dim3(256), 0, st>>>(bo.j, rs.nnz, (uint32_t)c0);
+					SPS_LAUNCH_CHECK();
+				}
+			}
+		}
+		SPS_HIP(hipStreamSynchronize(st));                          // (the block's workspace is handed back)
+		c->arena.rewind(mk);
+	}
+	*res = acc;
+	res->nnz_a = A.nnz; res->nnz_b = B.nnz;
+	if (!coo) {
+		uint32_t *noerr = c->arena.get<uint32_t>(1);
+		fill_zero(c, noerr, sizeof(uint32_t));
+		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS, noerr);
+		SPS_LAUNCH_CHECK();
+		const DigestSlot d = read_back(c, slots + DIGEST_SLOTS);
+		res->nnz = d.count; res->hash = d.hash; res->sum = d.sum;
+		if (row_nnz) { res->row_nnz = (const int64_t *)row_nnz; res->row_sum = row_sum; }
+		return;
+	}
+	// ---- interleave the blocks row by row
+	uint64_t total = 0;
+	for (auto &x : blocks.b) total += x.n;
+	OutSet &os = c->out[c->cur_out];
+	os.i.ensure((size_t)total * sizeof(int32_t)); os.j.ensure((size_t)total * sizeof(int32_t)); os.v.ensure((size_t)total * sizeof(double));
+	int32_t *oi = (int32_t *)os.i.p, *oj = (int32_t *)os.j.p; double *ov = (double *)os.v.p;
+	uint32_t *cnt = c->arena.get<uint32_t>(A.nrow ? A.nrow : 1), *cur = c->arena.get<uint32_t>(A.nrow ? A.nrow : 1);
+	int64_t *rowoff = c->arena.get<int64_t>((size_t)A.nrow + 1);
+	fill_zero(c, cnt, A.nrow * sizeof(uint32_t));
+	fill_zero(c, cur, A.nrow * sizeof(uint32_t));
+	auto block_rowptr = [&](const BlockOut &x) {
+		ConMat t; t.row = x.i; t.nnz = (uint32_t)x.n; t.nrow = A.nrow;
+		return dense_rowptr(c, t, 0);
+	};
+	for (auto &x : blocks.b) {
+		if (x.n >= (uint64_t(1) << 32)) throw Error{SPSAMD_EINVAL, "a column block of the product has 2^32 tuples or more"};
+		const Arena::Mark mk = c->arena.mark();
+		const uint32_t *rp = block_rowptr(x);
+		k_row_add_counts<<<dim3(grid_for(A.nrow)), dim3(256), 0, st>>>(rp, A.nrow, cnt);
+		SPS_LAUNCH_CHECK();
+		SPS_HIP(hipStreamSynchronize(st));
+		c->arena.rewind(mk);
+	}
+	scan_exclusive_u32_i64(c, cnt, rowoff, A.nrow);
+	for (auto &x : blocks.b) {
+		const Arena::Mark mk = c->arena.mark();
+		const uint32_t *rp = block_rowptr(x);
+		k_block_place<<<dim3(grid_for((size_t)x.n)), dim3(256), 0, st>>>(x.i, x.j, x.v, x.n, rp, rowoff, cur, oi, oj, ov);
+		SPS_LAUNCH_CHECK();
+		k_row_add_counts<<<dim3(grid_for(A.nrow)), dim3(256), 0, st>>>(rp, A.nrow, cur);
+		SPS_LAUNCH_CHECK();
+		SPS_HIP(hipStreamSynchronize(st));
+		c->arena.rewind(mk);
+	}
+	res->nnz = total;
+	res->idx0 = oi; res->idx1 = oj; res->val = ov;
+}
+
+void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
+{
+	const Arena::Mark mk = c->arena.mark();
+	uint64_t colblk = 0;
+	try {
+		spgemm_once(c, a, res);
+		return;
+	} catch (const TooWide &w) {
+		colblk = w.width;                                           // a heavy row and too many columns for one pass: block by block
+	}
+	SPS_HIP(hipStreamSynchronize(c->stream));
+	c->arena.rewind(mk);
+	const spsamd_result keep = *res;
+	*res = spsamd_result{};
+	res->shape0 = keep.shape0; res->shape1 = keep.shape1;
+	spgemm_column_blocks(c, a, res, colblk);
+	res->shape0 = keep.shape0; res->shape1 = keep.shape1;
 }
 
 } // namespace spsamd

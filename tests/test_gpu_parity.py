@@ -459,36 +459,76 @@ def test_two_contexts_on_two_threads(ctx):
     assert not errors, errors
 
 
-def test_heavy_row_capacity_limits_are_pinned(ctx):
-    """the windowed heavy-row path supports at most 2048 column windows of 16384 (ncol <= 2^25).  Beyond it
-    a product whose rows all stay at or below 4096 scalar products works as everywhere else, and one with a heavier
-    row is refused with SPSAMD_EINVAL and a message that names the limit (include/spsparse_amd.h, "Limits") -- never
-    a wrong result."""
+def test_heavy_rows_beyond_2_25_columns(ctx):
+    """the windowed heavy-row path indexes at most 2048 column windows of 16384 (ncol <= 2^25).  A wider
+    op(B) with a heavy row used to be refused (SPSAMD_EINVAL); it is now multiplied by column blocks of B (2^25 columns
+    at a time through the ordinary path, the blocks' outputs interleaved row by row) -- the row-wise oracle's tuples in
+    the oracle's order, in the COO sink, the digest sink, with scale vectors and a 'T' flag.  Products whose rows all
+    stay at or below 4096 scalar products never needed windows and take the ordinary path at any width."""
     from spsparse_amd import capi
-    ncol = (1 << 25) + 4096
+    ncol = 3 * (1 << 25) - 12345                     # three column blocks, the last one partial
     rng = np.random.default_rng(5)
     k = 6000
-    # B: k rows, one tuple each, columns spread over the whole (huge) range
-    bcols = np.sort(rng.choice(ncol, size=k, replace=False)).astype(np.int32)
-    B = orc.Mat(np.arange(k, dtype=np.int32), bcols, rng.random(k) + 0.5, (k, ncol))
-    # A: row 0 has 3000 tuples (3000 products: a mid row), row 1 has all 6000 (a heavy row)
-    light = orc.Mat(np.zeros(3000, np.int32), np.arange(3000, dtype=np.int32), rng.random(3000) + 0.5, (2, k))
+    # B: k rows, a few tuples each, columns spread over the whole (huge) range
+    per = 3
+    brow = np.repeat(np.arange(k, dtype=np.int32), per)
+    bcol = rng.integers(0, ncol, size=k * per).astype(np.int32)
+    bcol[:8] = [0, (1 << 25) - 1, 1 << 25, (1 << 25) + 1, (1 << 26) - 1, 1 << 26, ncol - 1, 5]      # block edges
+    B = orc.Mat(brow, bcol, rng.standard_normal(k * per), (k, ncol))
+    # A: row 0 a mid row (3000 products at most), rows 1..3 heavy (all of B's rows, half of them, ...), row 5 light
+    ai = np.concatenate([np.zeros(1000, np.int32), np.ones(k, np.int32), np.full(k // 2, 2, np.int32), np.full(2500, 3, np.int32), np.full(3, 5, np.int32)])
+    ak = np.concatenate([np.arange(1000), np.arange(k), np.arange(0, k, 2), rng.choice(k, 2500, replace=False), [1, 2, 3]]).astype(np.int32)
+    A = orc.Mat(ai, ak, rng.standard_normal(ai.size), (7, k))
+    light = orc.Mat(ai[:1000], ak[:1000], A.val[:1000], (7, k))
     got = _dev(ctx, light, B)
-    want = orc.multiply(light, B, rowwise=True)
-    _check(got, want)
+    _check(got, orc.multiply(light, B, rowwise=True))
     assert got[3].rows_heavy == 0 and got[3].rows_mid == 1
-    heavy = orc.Mat(np.ones(k, np.int32), np.arange(k, dtype=np.int32), rng.random(k) + 0.5, (2, k))
-    with pytest.raises(capi.SpsamdError, match="column windows") as ei:
-        _dev(ctx, heavy, B)
-    assert ei.value.code == -2
-    # the same heavy row at 2^25 columns exactly is inside the limit
+    want = orc.multiply(A, B, rowwise=True)
+    got = _dev(ctx, A, B)
+    _check(got, want)
+    assert got[3].rows_heavy >= 1 and got[3].window == 16384       # (per column block: a third of a row's products)
+    _, _, _, d = _dev(ctx, A, B, sink=capi.SINK_DIGEST)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s_) <= 1e-11 * np.abs(want[2]).sum()
+    # scale vectors (scalek over the wide dimension), C != 1, EXACT_PATTERN, and B given as its transpose
+    kcols = np.unique(bcol)
+    kcols = kcols[rng.uniform(size=kcols.size) < 0.7]              # (columns absent from scalek are skipped)
+    kw = dict(C_=-1.5, scalei=_rand_vec(rng, 7, 0.9), scalej=_rand_vec(rng, k, 0.9), scalek=orc.Vec(kcols, rng.uniform(0.5, 2, kcols.size), ncol))
+    want = orc.multiply(A, B, rowwise=True, **kw)
+    _check(_dev(ctx, A, B, flags=capi.SINK_EXACT_PATTERN, **kw), want)
+    Bt = orc.Mat(B.idx1, B.idx0, B.val, (ncol, k))
+    _check(_dev(ctx, A, Bt, tB="T", **kw), want)
+    # the same heavy rows at 2^25 columns exactly are inside the windowed path's range
     ncol2 = 1 << 25
-    bcols2 = np.sort(rng.choice(ncol2, size=k, replace=False)).astype(np.int32)
-    B2 = orc.Mat(np.arange(k, dtype=np.int32), bcols2, B.val, (k, ncol2))
-    got2 = _dev(ctx, heavy, B2)
-    want2 = orc.multiply(heavy, B2, rowwise=True)
-    _check(got2, want2)
-    assert got2[3].rows_heavy == 1 and got2[3].window == 16384
+    B2 = orc.Mat(brow, (bcol.astype(np.int64) % ncol2).astype(np.int32), B.val, (k, ncol2))
+    got2 = _dev(ctx, A, B2)
+    _check(got2, orc.multiply(A, B2, rowwise=True))
+    assert got2[3].rows_heavy >= 2 and got2[3].window == 16384
+
+
+@pytest.mark.parametrize("budget_mb", [1, 8])
+def test_window_indices_over_budget_go_by_column_blocks(ctx, budget_mb):
+    """ADVICE r1 #2, second half: the heavy rows' window indices take 12 bytes per row of op(B) and column window.  Where
+    they exceed what the device has left the product goes by column blocks narrow enough for them to fit; the knob
+    `index_budget_mb` sets the cap so that the path runs on a small matrix: same tuples, same digest as the oracle."""
+    from spsparse_amd import capi
+    a = wl.rmat(15, seed=9)                         # 32768 columns = 4 windows; 12 B x 32768 rows per window = 0.4 MB
+    A = orc.Mat(*a)
+    b = wl.rmat(15, seed=10)
+    B = orc.Mat(b[0], b[1], -b[2], b[3])
+    want = orc.multiply(A, B, rowwise=True, nthreads=8)
+    plain = _dev(ctx, A, B)
+    ctx.set_tuning("index_budget_mb", budget_mb)
+    try:
+        got = _dev(ctx, A, B)
+        _, _, _, d = _dev(ctx, A, B, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS)
+    finally:
+        ctx.set_tuning("index_budget_mb", 0)
+    _check(got, want)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s_) <= 1e-11 * np.abs(want[2]).sum()
+    if budget_mb == 1:
+        assert got[3].products == plain[3].products and got[3].rows_heavy > 0     # (two windows per block: every product once)
 
 
 def test_ablation_switch_is_not_in_the_shipped_library(monkeypatch):
