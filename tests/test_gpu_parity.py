@@ -603,7 +603,7 @@ def test_every_cell_scheme_against_the_oracle(ctx, knobs):
         assert res.products_tiles > 0
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPSAMD_STRESS_SEEDS", "30"))))
 def test_random_knobs_signs_and_flags(ctx, seed):
     """Differential stress of the heavy-row kernels: R-MAT operands of random scale (A*A and A*B), random signs, a random
     subset of the tuning knobs, the default and the EXACT_PATTERN flag, 'T' flags and C != 1 -- every draw against the
