@@ -17,8 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 VARIANT = os.environ.get("SPSAMD_VARIANT", "")
 LIBDIR = os.path.join(HERE, "lib", VARIANT) if VARIANT else os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspsparse_amd.so")
-SOURCES = ["prims.hip", "consolidate.hip", "spgemm.hip", "workload.hip", "capi.hip", "dist.hip"]
-HEADERS = ["internal.h", "devutil.h", "workload_common.h", os.path.join("..", "..", "include", "spsparse_amd.h")]
+SOURCES = ["prims.hip", "consolidate.hip", "spgemm.hip", "symbolic_heavy.hip", "k_light.hip", "k_hash.hip", "k_dense.hip", "k_tiles.hip",
+           "workload.hip", "capi.hip", "dist.hip"]
+HEADERS = ["internal.h", "devutil.h", "spgemm_dev.h", "spgemm_host.h", "spgemm_hash.h", "workload_common.h", os.path.join("..", "..", "include", "spsparse_amd.h")]
 # -ffp-contract=off: products and sums are rounded separately like the
 # reference's x86-64 build (`sum += a*b`, multiply_sparse.hpp:228,235).
 # -munsafe-fp-atomics: f64 atomic adds compile to ds_add_f64 / global_atomic_add_f64.
@@ -57,7 +58,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])

@@ -191,7 +191,7 @@ uint32_t *sorted_permutation(spsamd_ctx *c, const spsamd_coo *X, int lead);
 // Dense row pointer over all `nrow + extra` rows (extra trailing empty rows).
 uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra);
 
-// ---------------------------------------------------------------- multiply (spgemm.hip)
+// ---------------------------------------------------------------- multiply (spgemm.hip and the k_*.hip kernel files)
 
 struct ScaleDev {
 	bool present = false;

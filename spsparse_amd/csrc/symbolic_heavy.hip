@@ -1,0 +1,554 @@
+// symbolic_heavy.hip -- the heavy rows' symbolic phase: window index of B, window-major copy, per-row window histograms,
+// the grouping of windows into cells and tiles, the sorted cell lists.
+#include "spgemm_host.h"
+
+namespace spsamd {
+
+__global__ void k_cell_cost(const Cell *cells, uint32_t n, uint32_t fixed, uint32_t *cost)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cost[i] = cells[i].prods + fixed;
+}
+
+__global__ void k_xcd_bounds(const int64_t *pref, uint32_t n, uint32_t *xb)
+{
+	// xb[x] = first cell whose cost prefix reaches x/8 of the total
+	uint32_t x = threadIdx.x;
+	if (x > 8) return;
+	int64_t target = pref[n] / 8 * x;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (pref[mid] < target) lo = mid + 1; else hi = mid; }
+	xb[x] = x == 8 ? n : lo;
+}
+
+// ====================================================================== heavy rows: window index, cells
+
+// Window index of B: bwin[k * (nwin+1) + w] = first tuple of B row k whose
+// column is >= w * W  (bwin[k][0] = bptr[k], bwin[k][nwin] = bptr[k+1]).
+__global__ void k_bwin_prefill(const uint32_t *bptr, uint64_t nrowb, uint32_t nwin1, uint32_t *bwin)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t total = nrowb * nwin1;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < total; i += stride) bwin[i] = bptr[i / nwin1 + 1];
+}
+
+__global__ void k_bwin_fill(const int32_t *brow, const int32_t *bcol, const uint32_t *bptr, uint32_t nnzb, uint32_t wshift,
+	uint32_t nwin1, uint32_t *bwin)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= nnzb) return;
+	int32_t k = brow[e];
+	int w = (int)((uint32_t)bcol[e] >> wshift);
+	int wprev = (e > bptr[k]) ? (int)((uint32_t)bcol[e - 1] >> wshift) : -1;
+	for (int ww = wprev + 1; ww <= w; ++ww) bwin[(uint64_t)k * nwin1 + ww] = e;
+}
+
+// Tuples of B row k in window w as 16 bits (<= W <= 16384): half the bytes of the offset pairs for
+// the histogram below, which reads one whole row of this table per A tuple of a heavy row.  Rows
+// are padded to an even number of entries (nwp) so that two windows are read as one 32-bit word.
+__global__ void k_bwin_counts(const uint32_t *bwin, uint64_t nrowb, uint32_t nwin, uint32_t nwp, uint16_t *cnt)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t total = nrowb * nwp, stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < total; i += stride) {
+		const uint64_t k = i / nwp, w = i - k * nwp;
+		uint16_t v = 0;
+		if (w < nwin) { const uint32_t *bw = bwin + k * (nwin + 1) + w; v = (uint16_t)(bw[1] - bw[0]); }
+		cnt[i] = v;
+	}
+}
+
+// ---- window-major copy of B for the dense cells -------------------------------------------
+// A dense cell is one output row x ONE column window, and the cell lists are walked window by
+// window.  In the row-major array the tuples of window w are scattered over all of B (a few
+// tuples per 128-byte line belong to the window), and the index lookups bwin[k][w] touch one line
+// per B row.  The window-major copy puts the tuples of window w side by side, ordered by (k, col),
+// with a CSR row pointer per window: wptr[w * nrowb + k] .. [+1].  The working set of the
+// workgroups that are on window w is then |B_w| * 12 bytes plus a 4 * nrowb byte pointer slice,
+// and a row's pass over its A tuples (ascending k) moves forward through both.
+__global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_t nrowb, uint32_t nwin, uint32_t nwin1, uint16_t *cnt)
+{
+	__shared__ uint32_t tile[64][65];
+	const uint32_t k0 = blockIdx.x * 64u, w0 = blockIdx.y * 64u;
+	const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+	for (uint32_t ky = ty; ky < 64; ky += 4) {
+		const uint32_t k = k0 + ky;
+		if (k < nrowb) {
+			const uint32_t *row = bwin + (uint64_t)k * nwin1;
+			if (w0 + tx < nwin1) tile[ky][tx] = row[w0 + tx];
+			if (tx == 0 && w0 + 64 < nwin1) tile[ky][64] = row[w0 + 64];
+		}
+	}
+	__syncthreads();
+	for (uint32_t wy = ty; wy < 64; wy += 4) {
+		const uint32_t w = w0 + wy, k = k0 + tx;
+		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = (uint16_t)(tile[tx][wy + 1] - tile[tx][wy]);   // <= W tuples of one row in one window
+	}
+}
+
+__global__ void k_wm_scatter(const int32_t *brow, const int32_t *bcol, const double *bval, uint32_t nnzb, uint32_t wshift,
+	const uint32_t *bwin, uint32_t nwin1, const uint32_t *wptr, uint64_t nrowb, BTup *out)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= nnzb) return;
+	const uint32_t k = (uint32_t)brow[e], c = (uint32_t)bcol[e], w = c >> wshift;
+	const uint32_t dst = wptr[(uint64_t)w * nrowb + k] + (e - bwin[(uint64_t)k * nwin1 + w]);
+	const double v = bval[e];
+	BTup t; t.col = (int32_t)c; t.vlo = (uint32_t)__double2loint(v); t.vhi = (uint32_t)__double2hiint(v);
+	out[dst] = t;
+}
+
+// Per heavy row: products per column window.  One workgroup per row; a thread owns a PAIR of
+// windows (one 32-bit load per A tuple), sub-groups of threads take different tuples and every
+// thread keeps 8 tuples in flight.  A row's workgroup takes at most WH_HUB tuples; rows with more
+// are noted in a list and their remaining tuples are dealt in parts to a second launch that adds
+// into the row's histogram with global atomics (the longest hub row -- tens of thousands of tuples
+// -- would otherwise set the time of the whole kernel).
+constexpr int WH_NT = 256;
+constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
+constexpr uint32_t WH_HUB = 4096;            // tuples one workgroup takes
+constexpr uint32_t WH_HUB_MAX = 65536;       // list capacity (rows beyond it are finished by their own workgroup)
+
+__device__ __forceinline__ void win_hist_span(const RowMeta &m, const uint16_t *wcnt, uint32_t nwp, uint32_t beg, uint32_t end, uint32_t *s_cnt)
+{
+	const uint32_t npair = nwp >> 1;
+	const uint32_t *tab = (const uint32_t *)wcnt;                       // row k: npair words
+	uint32_t ppad = 1;
+	while (ppad < npair && ppad < WH_NT) ppad <<= 1;
+	const uint32_t nsub = ppad < WH_NT ? WH_NT / ppad : 1;
+	const uint32_t sub = threadIdx.x / ppad, p0 = threadIdx.x % ppad;
+	for (uint32_t p = p0; p < npair; p += ppad) {                       // one pass unless there are more than 256 pairs
+		uint32_t c0 = 0, c1 = 0;
+		uint32_t e = beg + sub;
+		for (; e + 7 * nsub < end; e += 8 * nsub) {
+			uint32_t x[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) x[u] = tab[(uint64_t)m.acol[e + u * nsub] * npair + p];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { c0 += x[u] & 0xFFFFu; c1 += x[u] >> 16; }
+		}
+		for (; e < end; e += nsub) { const uint32_t x = tab[(uint64_t)m.acol[e] * npair + p]; c0 += x & 0xFFFFu; c1 += x >> 16; }
+		if (c0) atomicAdd(&s_cnt[2 * p], c0);
+		if (c1) atomicAdd(&s_cnt[2 * p + 1], c1);
+	}
+}
+
+__global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, uint32_t *hubcount, uint32_t *hublist)
+{
+	__shared__ uint32_t s_cnt[WH_MAXW];
+	__shared__ uint32_t s_listed;
+	const uint32_t h = blockIdx.x, r = hrows[h];
+	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
+	for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
+	if (threadIdx.x == 0) {
+		uint32_t listed = 0;
+		if (end - beg > WH_HUB) {
+			const uint32_t slot = atomicAdd(hubcount, 1u);
+			if (slot < WH_HUB_MAX) { hublist[slot] = h; listed = 1; }
+		}
+		s_listed = listed;
+	}
+	__syncthreads();
+	win_hist_span(m, wcnt, nwp, beg, s_listed ? beg + WH_HUB : end, s_cnt);
+	__syncthreads();
+	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
+}
+
+// The tuples beyond WH_HUB of the listed rows, WH_HUB at a time: work item = (listed row, part).
+__global__ __launch_bounds__(WH_NT) void k_win_hist_hub(const uint32_t *hrows, RowMeta m, const uint16_t *wcnt,
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, const uint32_t *hubcount, const uint32_t *hublist)
+{
+	__shared__ uint32_t s_cnt[WH_MAXW];
+	const uint32_t nhub = min(*hubcount, WH_HUB_MAX);
+	// items are enumerated row by row; a workgroup finds its items by walking the (short) list
+	uint32_t item = 0;
+	for (uint32_t q = 0; q < nhub; ++q) {
+		const uint32_t h = hublist[q], r = hrows[h];
+		const uint32_t beg = m.beg[r] + WH_HUB, end = m.beg[r + 1];
+		const uint32_t parts = (end - beg + WH_HUB - 1) / WH_HUB;
+		for (uint32_t part = 0; part < parts; ++part, ++item) {
+			if (item % gridDim.x != blockIdx.x) continue;                 // uniform
+			for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
+			__syncthreads();
+			win_hist_span(m, wcnt, nwp, beg + part * WH_HUB, min(end, beg + (part + 1) * WH_HUB), s_cnt);
+			__syncthreads();
+			for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) { const uint32_t v = s_cnt[w]; if (v) atomicAdd(&winprod[(uint64_t)h * nwin + w], v); }
+			__syncthreads();
+		}
+	}
+}
+
+template <bool WRITE>
+__global__ void k_cells(const uint32_t *hrows, uint32_t nheavy, const uint32_t *rbeg, const int32_t *rid,
+	const uint32_t *winprod, uint32_t nwin, uint32_t cell_cap, uint32_t dense_min,
+	CellBases cnt, uint32_t *nseg, CellBases base, CellLists lists, const uint32_t *segbase, unsigned long long *clsprod,
+	TileKinds tk)
+{
+	uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+	if (h >= nheavy) return;
+	const uint32_t r = hrows[h];
+	Cell proto;
+	proto.beg = rbeg[r]; proto.end = rbeg[r + 1]; proto.rowid = rid[r]; proto.pad[0] = proto.pad[1] = 0;
+	const uint32_t *wp = winprod + (uint64_t)h * nwin;
+	uint32_t n[NCLS] = {};
+	unsigned long long np[NCLS + 2] = {};                              // + the two tile kinds
+	uint32_t ordinal = 0;
+	uint32_t cur = 0, start = 0, last = 0;
+	// rows with few A tuples: their hash / direct cells are grouped into tiles that share one expansion
+	const uint32_t L = proto.end - proto.beg;
+	const bool tileable = tk.k[0].enabled && L <= TILE_LMAX;
+	const bool direct_ok = tileable && tk.k[1].enabled;
+	// a hash cell of a row with many A tuples visits all of them whatever it holds: such rows get larger cells
+	if (tileable && tk.tile_cap > cell_cap) cell_cap = tk.tile_cap;      // tile cells may be larger than a hash table's (bitmap tiles)
+	if (!tileable && tk.long_cap > cell_cap) cell_cap = tk.long_cap;
+	// ... and their windows go to the dense kernel much earlier: walking a long row costs more than scanning the window
+	if (!tileable && tk.long_dense_min && tk.long_dense_min < dense_min) dense_min = tk.long_dense_min;
+	uint32_t lsh = 0;
+	while ((1u << lsh) < L) ++lsh;
+	const uint32_t G = min((uint32_t)TILE_NT >> lsh, TILE_MAXCELLS);
+	uint32_t ntc[2] = {0, 0}, ntl[2] = {0, 0};                        // tile cells / tiles emitted so far for this row
+	uint32_t tcnt[2] = {0, 0}, tcost[2] = {0, 0}, tprods[2] = {0, 0}, tfirst[2] = {0, 0}, twa0[2] = {0, 0};   // the open tiles
+	auto close_tile = [&](int kd) {
+		if (!tcnt[kd]) return;
+		if (WRITE) {
+			Tile t; t.beg = proto.beg; t.end = proto.end; t.rowid = proto.rowid; t.first = tk.k[kd].tcbase[h] + tfirst[kd]; t.ncells = tcnt[kd];
+			t.wa0 = twa0[kd]; t.prods = tprods[kd]; t.pad = 0;
+			tk.k[kd].tiles[tk.k[kd].tlbase[h] + ntl[kd]] = t;
+		}
+		++ntl[kd]; tcnt[kd] = 0; tcost[kd] = 0; tprods[kd] = 0;
+	};
+	// cost of a cell against the tile's capacity: products for a hash tile; for a direct tile an upper bound of its
+	// ITEMS (R tuples each, at most one partial item per A tuple) rounded up to whole 64-item blocks
+	auto tile_cell = [&](int kd, uint32_t wa, uint32_t wb, uint32_t prods) {
+		const uint32_t cost = tk.k[kd].by_items ? ((prods / DENSE_R + L + 63u) & ~63u) + 64u : prods;
+		if (tcnt[kd] == G || tcost[kd] + cost > tk.k[kd].pb) close_tile(kd);
+		if (!tcnt[kd]) { tfirst[kd] = ntc[kd]; twa0[kd] = wa; }
+		if (WRITE) {
+			TCell tc; tc.wa = (uint16_t)wa; tc.wb = (uint16_t)wb; tc.seg = segbase ? segbase[r] + ordinal : 0; tc.prods = prods;
+			tk.k[kd].tcells[tk.k[kd].tcbase[h] + ntc[kd]] = tc;
+		}
+		++ntc[kd]; ++tcnt[kd]; tcost[kd] += cost; tprods[kd] += prods;
+		np[NCLS + kd] += prods;
+		++ordinal;
+	};
+	auto flush = [&]() {
+		if (!cur) return;
+		if (tileable && cur <= tk.tile_cap) {
+			tile_cell(0, start, last + 1, cur);
+			cur = 0;
+			return;
+		}
+		int cls = hash_class(cur);
+		if (WRITE) {
+			Cell c = proto; c.seg = segbase ? segbase[r] + ordinal : 0; c.prods = cur; c.wa = (uint16_t)start; c.wb = (uint16_t)(last + 1);
+			lists.list[cls][base.base[cls][h] + n[cls]] = c;
+		}
+		++n[cls]; np[cls] += cur; ++ordinal; cur = 0;
+	};
+	// the alternative tile scheme's cell count (counting pass only): same greedy grouping with its own cap and span
+	uint32_t alt_cur = 0, alt_start = 0, alt_n = 0;
+	const bool alt_on = !WRITE && tk.alt_cells && tileable;
+	// the row's histogram is read four windows per load where the row is 16-byte aligned (one thread per
+	// row: consecutive threads are a whole row apart, so narrow loads waste most of every cache line)
+	const bool vec4 = (nwin & 3u) == 0;
+	uint4 quad = make_uint4(0, 0, 0, 0);
+	for (uint32_t w = 0; w < nwin; ++w) {
+		uint32_t c;
+		if (vec4) {
+			if ((w & 3u) == 0) quad = *reinterpret_cast<const uint4 *>(wp + w);
+			c = (w & 3u) == 0 ? quad.x : ((w & 3u) == 1 ? quad.y : ((w & 3u) == 2 ? quad.z : quad.w));
+		} else c = wp[w];
+		if (alt_on) {
+			if (c > dense_min || (direct_ok && c > tk.direct_min)) { if (alt_cur) { ++alt_n; alt_cur = 0; } }
+			else if (c > 0) {
+				if (alt_cur && (alt_cur + c > tk.alt_cap || (tk.alt_span && w - alt_start >= tk.alt_span))) { ++alt_n; alt_cur = 0; }
+				if (!alt_cur) alt_start = w;
+				alt_cur += c;
+			}
+		}
+		if (c > dense_min) {
+			flush();
+			if (WRITE) {
+				Cell d = proto; d.seg = segbase ? segbase[r] + ordinal : 0; d.prods = c; d.wa = (uint16_t)w; d.wb = (uint16_t)(w + 1);
+				lists.list[CLS_DENSE][base.base[CLS_DENSE][h] + n[CLS_DENSE]] = d;
+			}
+			++n[CLS_DENSE]; np[CLS_DENSE] += c; ++ordinal;
+		} else if (direct_ok && c > tk.direct_min) {
+			// one window of a tile row with enough products to pay for a cell of its own: direct cell
+			flush();
+			tile_cell(1, w, w + 1, c);
+		} else if (c > cell_cap) {
+			// too large for a group, too small for a dense window: a hash cell of its own
+			flush();
+			cur = c; start = last = w;
+			flush();
+		} else if (c > 0) {
+			if (cur + c > cell_cap || (cur && tileable && tk.span_cap && w - start >= tk.span_cap)) flush();
+			if (!cur) start = w;
+			cur += c; last = w;
+		}
+	}
+	flush();
+	close_tile(0);
+	close_tile(1);
+	if (!WRITE) {
+#pragma unroll
+		for (int k = 0; k < NCLS; ++k) cnt.base[k][h] = n[k];
+		for (int k = 0; k < NCLS + 2; ++k) if (np[k]) atomicAdd(&clsprod[k], np[k]);
+		nseg[r] = ordinal;
+		for (int kd = 0; kd < 2; ++kd) if (tk.k[kd].enabled) { tk.k[kd].ntc[h] = ntc[kd]; tk.k[kd].ntl[h] = ntl[kd]; }
+		if (alt_on) { if (alt_cur) ++alt_n; if (alt_n) atomicAdd(tk.alt_cells, (unsigned long long)alt_n); if (ntc[0]) atomicAdd(tk.alt_cells + 1, (unsigned long long)ntc[0]); }
+	}
+}
+
+__global__ void k_tile_keys(const Tile *tiles, uint32_t n, uint64_t *keys)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) keys[i] = tiles[i].wa0;             // window-major, stable
+}
+
+__global__ void k_gather_tiles(const Tile *src, const uint32_t *perm, uint32_t n, Tile *dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[perm[i]];
+}
+
+__global__ void k_cell_keys(const Cell *cells, uint32_t n, int by_size, uint64_t *keys)
+{
+	// window-major; inside a window the largest cells first (dense) or input order (hash: stable sort)
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint64_t w = cells[i].wa;
+	// size in units of 256 products, 16 bits (cells beyond 2^24 products rank equal): a 16-bit minor key = 2 sort passes
+	const uint32_t sz = min(cells[i].prods >> 8, 0xFFFFu);
+	keys[i] = by_size ? ((w << 16) | (uint64_t)(0xFFFFu - sz)) : w;
+}
+
+__global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n, Cell *dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[perm[i]];
+}
+
+static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift)
+{
+	hipStream_t st = c->stream;
+	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
+	uint16_t *cnt = c->arena.get<uint16_t>(total);
+	hv.wptr = c->arena.get<uint32_t>(total + 1);
+	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(hv.bwin, (uint32_t)nrowb, hv.nwin, hv.nwin1, cnt);
+	SPS_LAUNCH_CHECK();
+	scan_exclusive_u16_u32(c, cnt, hv.wptr, total);
+	hv.btw = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);
+	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
+	SPS_LAUNCH_CHECK();
+}
+
+// Heavy rows: window index of B, per-row window histogram, counting pass of the cell grouping.
+void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
+	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern)
+{
+	hipStream_t st = c->stream;
+	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
+	if (c->tune.window == 8192 || c->tune.window == 16384) hv.W = c->tune.window;
+	const uint32_t wshift = hv.W == 8192 ? 13 : 14;
+	hv.nwin = (uint32_t)((B.ncol + hv.W - 1) >> wshift);
+	if (hv.nwin > (uint32_t)WH_MAXW) throw TooWide{COLBLK};         // spgemm() then multiplies by column blocks of B
+	hv.nwin1 = hv.nwin + 1;
+	const uint64_t nrowb = B.nrow + extra;
+	{
+		// The window indices (bwin, its 16-bit counts, the window-major pointer with its counts, the heavy rows' histograms)
+		// grow with rows(B) x windows: 12 bytes per B row and window.  Where they would not fit what the device has left
+		// (or the cap a test sets), the product goes by column blocks narrow enough for them to fit.
+		const uint64_t per_window = nrowb * 12u + (uint64_t)hv.n * 4u;
+		uint64_t budget;
+		const uint64_t room = c->arena.slabs.empty() ? 0 : c->arena.slabs.back().cap - c->arena.slabs.back().used;
+		if (c->tune.index_budget_mb > 0) budget = (uint64_t)c->tune.index_budget_mb << 20;
+		else if (per_window * (hv.nwin + 1ull) <= room) budget = room;  // (the steady state: the workspace of an earlier call holds them)
+		else {
+			size_t freeb = 0, totalb = 0;
+			SPS_HIP(hipMemGetInfo(&freeb, &totalb));
+			budget = (uint64_t)((double)(freeb + room) * 0.8);
+		}
+		if (per_window * (hv.nwin + 1ull) > budget && hv.nwin > 1) {
+			uint64_t fit = budget / per_window;                         // windows per block that fit
+			if (fit < 2) throw Error{SPSAMD_ENOMEM, "the window index of one column window of op(B) does not fit the device"};
+			uint64_t w2 = 1;
+			while (w2 * 2 <= fit - 1) w2 *= 2;
+			throw TooWide{w2 << wshift};
+		}
+	}
+	hv.nrowb = nrowb;
+	hv.nnzb = B.nnz;
+	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
+	k_bwin_prefill<<<dim3(4096), dim3(256), 0, st>>>(bptr, nrowb, hv.nwin1, hv.bwin);
+	SPS_LAUNCH_CHECK();
+	k_bwin_fill<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, bptr, B.nnz, wshift, hv.nwin1, hv.bwin);
+	SPS_LAUNCH_CHECK();
+	hv.rows = bins.rows + bins.off[8];
+	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
+	const uint32_t nwp = (hv.nwin + 1u) & ~1u;
+	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * nwp);
+	k_bwin_counts<<<dim3(4096), dim3(256), 0, st>>>(hv.bwin, nrowb, hv.nwin, nwp, wcnt);
+	SPS_LAUNCH_CHECK();
+	uint32_t *hubcount = c->arena.get<uint32_t>(1);
+	uint32_t *hublist = c->arena.get<uint32_t>(WH_HUB_MAX);
+	fill_zero(c, hubcount, sizeof(uint32_t));
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
+	SPS_LAUNCH_CHECK();
+	k_win_hist_hub<<<dim3((unsigned)c->num_cu * 4u), dim3(WH_NT), 0, st>>>(hv.rows, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
+	SPS_LAUNCH_CHECK();
+	for (int k = 0; k < NCLS; ++k) {
+		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
+		hv.base.base[k] = c->arena.get<uint32_t>((size_t)hv.n + 1);
+	}
+	if (c->tune.cell_cap >= 64 && c->tune.cell_cap <= (int)CELL_CAP) hv.cell_cap = (uint32_t)c->tune.cell_cap;
+	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
+	// (a window between dense_min and cell_cap products becomes a dense cell; smaller ones are grouped up to cell_cap)
+	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
+	hv.tb.enabled = !c->tune.no_tiles;
+	// Tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles v2.
+	// ORDERED runs on the first generation (the variant that exists), EXACT_PATTERN on the bitmap tiles or the hash tiles v2;
+	// otherwise the choice is made per call below, by counting the cells either scheme would cut.
+	const bool free_choice = !ordered && c->tune.tiles_v1 == 0;
+	const bool user_dense_min = c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP;
+	auto set_scheme = [&](int scheme) {
+		hv.tiles2 = scheme;
+		if (!user_dense_min) hv.dense_min = scheme == 0 && hv.tb.enabled ? DENSE_MIN_BITMAP : DENSE_MIN_DEFAULT;
+		hv.tb.by_items = scheme != 1 ? 1 : 0;
+		hv.tb.pb = scheme != 1 ? (uint32_t)TILE2_ITEMS : (hv.coo ? (uint32_t)TILE_PB_STORE : (uint32_t)TILE_PB);
+		hv.span_cap = scheme == 0 ? (uint32_t)BM_WORDS >> (wshift - 6) : 0u;
+	};
+	set_scheme(ordered ? 1 : (c->tune.tiles_v1 == 1 ? (pattern ? 2 : 1) : (c->tune.tiles_v1 == 2 ? 2 : 0)));
+	// Rows too long for a tile: a hash-class cell of theirs reads B in row-major pieces of 4.4 tuples on average -- 6x the
+	// algorithmic bytes from HBM at line granularity (FETCH_SIZE of k_hash<3072>: 14.8 GB for 2.5 GB) -- while the dense kernel
+	// reads the window-major copy.  Their windows go to k_dense from LONG_DENSE_MIN products on.  R-MAT A*A, ms per step:
+	//   threshold   scale 19   scale 20 (cfg2)   scale 21
+	//     2048        26.9        78.1             251 (1536: 247.5)
+	//     1024         -          76.9             250.6
+	//      512        27.0        76.8             260.9
+	//      128        27.2        76.5             272.3
+	// (at scale 21 the same rows spread over twice the windows: a dense cell's walk over the row's A tuples and its scan of
+	// all W slots buy half the products).  1024 keeps most of scale 20's gain and costs scale 21 about 1 %.
+	// (8192-column windows only: the 16384-column dense kernel runs one workgroup per CU and wants full windows -- scale 23:
+	// 2.49 s with 128, 2.40 with 512, 2.26 with the general threshold)
+	hv.long_dense_min = c->tune.long_dense_min > 0 ? (uint32_t)c->tune.long_dense_min : (hv.W == 8192 ? LONG_DENSE_MIN_DEFAULT : 0u);
+	hv.long_cap = c->tune.long_cap > 0 ? (uint32_t)std::min<int>(c->tune.long_cap, (int)CELL_CAP) : 0u;
+	hv.tb2.by_items = 1;
+	// direct cells need the window-major copy of B and are not used for ordered (ascending-k) sums
+	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
+	hv.tb2.enabled = hv.tb.enabled && !c->tune.no_wmajor && !ordered && !pattern && hv.direct_min < hv.dense_min;
+	hv.tb2.pb = (uint32_t)hv.W;      // items of a direct tile: one bit each in a W-bit bitmap
+	for (TileBases *t : {&hv.tb, &hv.tb2}) {
+		t->ntc = c->arena.get<uint32_t>(hv.n); t->ntl = c->arena.get<uint32_t>(hv.n);
+		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
+	}
+	auto count_pass = [&]() {
+		fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
+		for (TileBases *t : {&hv.tb, &hv.tb2}) { fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t)); }
+		k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, tile_kinds(hv));
+		SPS_LAUNCH_CHECK();
+	};
+	if (free_choice && hv.tb.enabled) {
+		// Bitmap tiles hold 4096 products per cell but at most 16 windows of columns; hash tiles 2048 products over any
+		// range.  Per-cell bookkeeping is most of a tile kernel's time, so the scheme that cuts clearly fewer cells wins;
+		// break-even measured near 1.4 bitmap cells per hash cell (R-MAT A*A: scale 20, 3.22 M against 3.85 M cells: bitmap,
+		// 34.8 vs 39+ ms; scale 21, 11.4 M against 12.2 M: bitmap, 236 vs 247 ms; scale 22, 42.6 M against 29.8 M: 727 vs
+		// 731 ms; scale 23 -- sparse rows spread over 512 windows, 150 M against 65 M -- hash, 0.95 vs 1.35 s).  The counting
+		// pass of the bitmap scheme also counts the cells the hash scheme would cut; only where that one wins is it repeated.
+		set_scheme(0);
+		hv.alt_cap = (uint32_t)(TILE_T / 2); hv.alt_span = 0;
+		hv.alt_cells = c->arena.get<unsigned long long>(2);          // [0] cells of the hash scheme, [1] of the bitmap scheme
+		fill_zero(c, hv.alt_cells, 2 * sizeof(unsigned long long));
+		count_pass();
+		WordList wl; wl.add64(hv.alt_cells); wl.add64(hv.alt_cells + 1);
+		uint32_t hw[4];
+		read_back_words(c, wl, hw);
+		const unsigned long long cells_hash = (unsigned long long)hw[0] | ((unsigned long long)hw[1] << 32);
+		const unsigned long long cells_bm = (unsigned long long)hw[2] | ((unsigned long long)hw[3] << 32);
+		hv.alt_cells = nullptr;
+		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %llu hash %llu\n", cells_bm, cells_hash);
+		if (cells_bm * 100u > cells_hash * 140u) { set_scheme(2); count_pass(); }
+	} else count_pass();
+	// every per-row counter of the grouping scanned in one batch, every total read back in one round trip
+	ScanBatch sb;
+	for (int k = 0; k < NCLS; ++k) sb.add(hv.cnt.base[k], hv.base.base[k]);
+	sb.add(hv.tb.ntc, hv.tb.tcbase); sb.add(hv.tb.ntl, hv.tb.tlbase);
+	sb.add(hv.tb2.ntc, hv.tb2.tcbase); sb.add(hv.tb2.ntl, hv.tb2.tlbase);
+	static_assert(NCLS + 4 <= SCAN_BATCH_MAX && NCLS + 4 + 2 * (NCLS + 2) <= WORD_LIST_MAX, "batch sizes");
+	scan_exclusive_u32_batch(c, sb, hv.n);
+	WordList wl;
+	for (int k = 0; k < NCLS; ++k) wl.add(hv.base.base[k] + hv.n);
+	wl.add(hv.tb.tcbase + hv.n); wl.add(hv.tb.tlbase + hv.n); wl.add(hv.tb2.tcbase + hv.n); wl.add(hv.tb2.tlbase + hv.n);
+	for (int k = 0; k < NCLS + 2; ++k) wl.add64(clsprod + k);
+	uint32_t hw[WORD_LIST_MAX];
+	read_back_words(c, wl, hw);
+	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = hw[k];
+	hv.ntcell = hw[NCLS]; hv.ntile = hw[NCLS + 1]; hv.ntcell2 = hw[NCLS + 2]; hv.ntile2 = hw[NCLS + 3];
+	for (int k = 0; k < NCLS + 2; ++k) hv.clsprod[k] = (unsigned long long)hw[NCLS + 4 + 2 * k] | ((unsigned long long)hw[NCLS + 5 + 2 * k] << 32);
+	if ((hv.ncell[CLS_DENSE] || hv.ntile2) && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
+}
+
+// Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.
+void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase)
+{
+	hipStream_t st = c->stream;
+	int wbits = 1;                                   // bits of a window index: the cell lists are sorted on as few digits as needed
+	while ((1u << wbits) < hv.nwin) ++wbits;
+	CellLists lists;
+	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
+	hv.tb.tcells = c->arena.get<TCell>(hv.ntcell ? hv.ntcell : 1);
+	hv.tb.tiles = c->arena.get<Tile>(hv.ntile ? hv.ntile : 1);
+	hv.tb2.tcells = c->arena.get<TCell>(hv.ntcell2 ? hv.ntcell2 : 1);
+	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
+	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, tile_kinds(hv));
+	SPS_LAUNCH_CHECK();
+	for (int kd = 0; kd < 2; ++kd) {
+		TileBases &t = kd ? hv.tb2 : hv.tb;
+		const uint32_t nd = kd ? hv.ntile2 : hv.ntile;
+		if (nd < 2) continue;
+		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
+		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
+		k_tile_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(t.tiles, nd, k0);
+		SPS_LAUNCH_CHECK();
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, wbits);
+		Tile *sorted = c->arena.get<Tile>(nd);
+		k_gather_tiles<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(t.tiles, where ? p1 : p0, nd, sorted);
+		SPS_LAUNCH_CHECK();
+		t.tiles = sorted;
+	}
+	for (int k = 0; k < NCLS; ++k) {
+		uint32_t nd = hv.ncell[k];
+		if (nd < 2) continue;
+		uint64_t *k0 = c->arena.get<uint64_t>(nd), *k1 = c->arena.get<uint64_t>(nd);
+		uint32_t *p0 = c->arena.get<uint32_t>(nd), *p1 = c->arena.get<uint32_t>(nd);
+		k_cell_keys<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == CLS_DENSE, k0);
+		SPS_LAUNCH_CHECK();
+		int where = radix_sort_pairs(c, k0, p0, k1, p1, nd, k == CLS_DENSE ? 16 + wbits : wbits);
+		Cell *sorted = c->arena.get<Cell>(nd);
+		k_gather_cells<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], where ? p1 : p0, nd, sorted);
+		SPS_LAUNCH_CHECK();
+		hv.cells[k] = sorted;
+	}
+	// Measured on R-MAT scale-20: giving each XCD its own part of the list is SLOWER (dense 80 vs
+	// 57 ms, hash 73 vs 62 ms) than letting all XCDs walk the same windows together, so the
+	// partition stays an experiment behind SPSAMD_XCD=1.
+	const bool xcd_aware = c->tune.xcd != 0;
+	for (int k = 0; k < NCLS && xcd_aware; ++k) {
+		uint32_t nd = hv.ncell[k];
+		if (nd < 4096) continue;
+		uint32_t *cost = c->arena.get<uint32_t>(nd);
+		int64_t *pref = c->arena.get<int64_t>((size_t)nd + 1);
+		k_cell_cost<<<dim3(grid_for(nd)), dim3(256), 0, st>>>(hv.cells[k], nd, k == CLS_DENSE ? 6000u : 2000u, cost);
+		SPS_LAUNCH_CHECK();
+		scan_exclusive_u32_i64(c, cost, pref, nd);
+		hv.xb[k] = c->arena.get<uint32_t>(9);
+		k_xcd_bounds<<<dim3(1), dim3(64), 0, st>>>(pref, nd, hv.xb[k]);
+		SPS_LAUNCH_CHECK();
+	}
+}
+
+
+} // namespace spsamd
