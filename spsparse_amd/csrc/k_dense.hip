@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 				s_cpref[rank] = myfirst;
 				s_cse[rank] = make_uint2(lo, lo + len);
 				s_caval[rank] = a;
-				if (myfirst < (uint32_t)W) atomicOr(&s_bmask[myfirst >> 6], 1ull << (myfirst & 63u));
+				if (myfirst < (uint32_t)W) atomicOr(reinterpret_cast<uint32_t *>(s_bmask) + (myfirst >> 5), 1u << (myfirst & 31u));     // (32-bit halves: half the bank traffic)
 			}
 			if (ABL(ep, 8)) total = 0;
 			if (total == 0) { lo = lo2; len = hi2 - lo2; a = a2; continue; }     // uniform (nothing was marked)

@@ -593,7 +593,7 @@ __device__ __forceinline__ void tile_expand(TileX<NT, NWORD> &X, uint32_t lsh, u
 		X.cpref[rank] = (uint16_t)myfirst;
 		X.cse[rank] = make_uint2(lo, lo + len);
 		X.caval[rank] = a;
-		atomicOr(&X.bmask[myfirst >> 6], 1ull << (myfirst & 63u));
+		atomicOr(reinterpret_cast<uint32_t *>(X.bmask) + (myfirst >> 5), 1u << (myfirst & 31u));
 	}
 	if (myei == 0 && myc < ncells) { X.cellI[myc] = myfirst; X.cellseg[myc] = myseg; X.cellw[myc] = myw; }    // a cell's first thread: its items start here
 	if (tid == 0) X.cellI[ncells] = total;
