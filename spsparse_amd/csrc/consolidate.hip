@@ -309,11 +309,24 @@ __global__ void k_rowptr(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t
 	ptr[r] = lo;
 }
 
+// The same from the tuples' side: tuple t (and the end, t = n) writes the entries of the rows between its predecessor's row
+// and its own -- one streaming pass over the row indices instead of a binary search per row (cfg3, 8.4e7 tuples in 1.7e7
+// rows: 0.41 -> 0.1 ms).  A thread loops over a GAP of empty rows, so this form is for operands without huge ones.
+__global__ void k_rowptr_scatter(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t *ptr)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n) return;
+	const uint64_t first = t == 0 ? 0 : (uint64_t)(uint32_t)row[t - 1] + 1;       // entries below were written by earlier tuples
+	const uint64_t last = t == n ? nptr : std::min<uint64_t>((uint64_t)(uint32_t)row[t] + 1, nptr);   // [first, last) = rows r with ptr[r] = t
+	for (uint64_t r = first; r < last; ++r) ptr[r] = (uint32_t)t;
+}
+
 uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra)
 {
 	uint64_t nptr = m.nrow + 1 + extra;
 	uint32_t *ptr = c->arena.get<uint32_t>(nptr);
-	k_rowptr<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+	if (nptr <= 8ull * m.nnz + 1024) k_rowptr_scatter<<<dim3(grid_for((size_t)m.nnz + 1)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+	else k_rowptr<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);     // (mostly empty rows: a search per pointer entry)
 	SPS_LAUNCH_CHECK();
 	return ptr;
 }
