@@ -23,9 +23,10 @@ static int bits_for(uint64_t dim)
 __global__ void k_inspect(const int32_t *major, const int32_t *minor, const double *val, size_t n,
 	uint64_t nrow, uint64_t ncol, int zero_nan, uint32_t *flags)
 {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	// grid-stride: a wave raises the shared flag word ONCE, after all its elements (one read of that word per element, then per
+	// wave of 64 elements, was most of this kernel's time on large operands)
 	uint32_t f = 0;
-	if (i < n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		int32_t r = major[i], c = minor[i];
 		if (r < 0 || (uint64_t)r >= nrow || c < 0 || (uint64_t)c >= ncol) f |= 1u;
 		double v = val[i];
@@ -33,11 +34,10 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 		if (i > 0) {
 			int32_t pr = major[i - 1], pc = minor[i - 1];
 			if (!(pr < r || (pr == r && pc < c))) f |= 2u;
+			if (!(pc < c || (pc == c && pr <= r))) f |= 4u;         // not in (minor, major) order either (ties allowed)
 		}
 	}
-	// almost every thread of an unsorted operand raises bit 1: one lane per wave speaks for it, and tests the flag
-	// word before the atomic (16 M reads of one address were most of this kernel's time)
-	const uint32_t wf = (__ballot(f & 1u) ? 1u : 0u) | (__ballot(f & 2u) ? 2u : 0u);
+	const uint32_t wf = (__ballot(f & 1u) ? 1u : 0u) | (__ballot(f & 2u) ? 2u : 0u) | (__ballot(f & 4u) ? 4u : 0u);
 	if (wf && lane_id() == 0 && (*(volatile uint32_t *)flags & wf) != wf) atomicOr(flags, wf);
 }
 
@@ -175,7 +175,7 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 
 	uint32_t *flags = c->arena.get<uint32_t>(2);
 	fill_zero(c, flags, 2 * sizeof(uint32_t));
-	k_inspect<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, dv, n, out->nrow, out->ncol, zero_nan, flags);
+	k_inspect<<<dim3(std::min(grid_for(n), 8192u)), dim3(256), 0, c->stream>>>(major, minor, dv, n, out->nrow, out->ncol, zero_nan, flags);
 	SPS_LAUNCH_CHECK();
 	uint32_t f = read_back(c, flags);
 	if (f & 1u) throw Error{SPSAMD_EINVAL, "Sparse index out of bounds (VectorCooArray::add would reject it, VectorCooArray.hpp:246-262)"};
@@ -197,7 +197,11 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	uint32_t *pay0 = c->arena.get<uint32_t>(n), *pay1 = c->arena.get<uint32_t>(n);
 	k_build_keys<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, n, mb, keys0);
 	SPS_LAUNCH_CHECK();
-	int where = radix_sort_pairs(c, keys0, pay0, keys1, pay1, n, mb + Mb);
+	// An operand that is in (minor, major) order -- a matrix kept sorted by rows and used with 'T', cfg5's R -- needs the stable
+	// passes over the MAJOR digits only: an LSD sort that skips the low digits leaves ties in input order, which is the minor
+	// order already (Galerkin 256^3, R^T: 3 passes instead of 6).
+	const int low_bit = (f & 4u) ? 0 : mb;
+	int where = radix_sort_pairs(c, keys0, pay0, keys1, pay1, n, mb + Mb, low_bit);
 	uint64_t *ks = where ? keys1 : keys0;
 	uint32_t *ps = where ? pay1 : pay0;
 	uint64_t *kk = where ? keys0 : keys1;      // the other key buffer is free now

@@ -136,10 +136,11 @@ struct WordList { const uint32_t *p[WORD_LIST_MAX]; int count = 0;
 	int add64(const void *q) { const int at = add(q); add((const uint32_t *)q + 1); return at; } };
 void read_back_words(spsamd_ctx *c, const WordList &w, uint32_t *host);
 
-// Stable LSD radix sort of (key, payload) pairs on key bits [0, key_bits).
+// Stable LSD radix sort of (key, payload) pairs on key bits [low_bit, key_bits) (a caller whose input is already in the
+// order of the low bits skips their passes).
 // Returns which of the two buffer pairs holds the result (0: keys0/pay0, 1: keys1/pay1).
 int radix_sort_pairs(spsamd_ctx *c, uint64_t *keys0, uint32_t *pay0, uint64_t *keys1, uint32_t *pay1,
-	size_t n, int key_bits);
+	size_t n, int key_bits, int low_bit = 0);
 
 void fill_u32(spsamd_ctx *c, uint32_t *p, uint32_t v, size_t n);
 void fill_zero(spsamd_ctx *c, void *p, size_t bytes);
