@@ -888,6 +888,38 @@ def test_presorted_operands(ctx):
     _check(_dev(ctx, A, B), want)
 
 
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_row_sorted_operand_used_transposed(ctx, policy):
+    """An operand stored in (row, column) order -- with duplicate tuples, explicit zeros and NaNs, not declared sorted -- and
+    used with 'T': its consolidation by columns sorts on the major digits only (the LSD passes over the low digits are
+    skipped: the ties stay in input order, which is the minor order already).  Both as A and as B, every duplicate
+    policy, against the oracle; and the stand-alone consolidate by {1, 0} of the same tuples."""
+    rng = np.random.default_rng(31 + policy)
+    n, m = 3000, 70000
+    i0 = np.sort(rng.integers(0, 300, n)).astype(np.int32)                  # rows ascending, many per row
+    i1 = rng.integers(0, m, n).astype(np.int32)
+    order = np.lexsort((i1, i0))
+    i0, i1 = i0[order], i1[order]
+    dup = rng.integers(0, n - 1, 400)
+    i0[dup + 1], i1[dup + 1] = i0[dup], i1[dup]                              # duplicate tuples, adjacent (still in order)
+    order = np.lexsort((i1, i0), )
+    i0, i1 = i0[order], i1[order]
+    v = rng.standard_normal(n)
+    v[rng.integers(0, n, 60)] = 0.0
+    X = orc.Mat(i0, i1, v, (300, m))                                       # sort0 = -1: nothing declared
+    Y = _rand_mat(rng, (300, 40), 2000)
+    kw = dict(duplicate_policy=policy)
+    _check(_dev(ctx, X, Y, tA="T", **kw), orc.multiply(X, Y, rowwise=True, tA="T", **kw))        # (m x 300) * (300 x 40)
+    Z = _rand_mat(rng, (25, m), 4000)
+    _check(_dev(ctx, Z, X, tB="T", **kw), orc.multiply(Z, X, rowwise=True, tB="T", **kw))        # (25 x m) * (m x 300)
+    from spsparse_amd import capi
+    sx, keep = capi.host_coo(X.idx0, X.idx1, X.val, X.shape)
+    r = ctx.consolidate(sx, 1, policy)
+    gi, gj, gv = ctx.fetch(r)
+    w0, w1, wv = orc.consolidate(X.idx0, X.idx1, X.val, 1, policy)
+    assert np.array_equal(gi, w0) and np.array_equal(gj, w1) and np.array_equal(gv, wv)
+
+
 def test_consolidate_known_answer(ctx):
     """tests/test_array.cpp:135-168 through spsamd_consolidate"""
     from spsparse_amd import capi
