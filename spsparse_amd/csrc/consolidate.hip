@@ -30,14 +30,16 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 		int32_t r = major[i], c = minor[i];
 		if (r < 0 || (uint64_t)r >= nrow || c < 0 || (uint64_t)c >= ncol) f |= 1u;
 		double v = val[i];
-		if (v == 0 || (zero_nan && v != v)) f |= 2u;
+		if (v == 0 || (zero_nan && v != v)) f |= 2u | 8u;         // 8: a value consolidate() may drop
 		if (i > 0) {
 			int32_t pr = major[i - 1], pc = minor[i - 1];
 			if (!(pr < r || (pr == r && pc < c))) f |= 2u;
-			if (!(pc < c || (pc == c && pr <= r))) f |= 4u;         // not in (minor, major) order either (ties allowed)
+			if (!(pc < c || (pc == c && pr < r))) f |= 4u;          // not STRICTLY in (minor, major) order either
 		}
 	}
-	const uint32_t wf = (__ballot(f & 1u) ? 1u : 0u) | (__ballot(f & 2u) ? 2u : 0u) | (__ballot(f & 4u) ? 4u : 0u);
+	uint32_t wf = 0;
+#pragma unroll
+	for (uint32_t b = 1u; b <= 8u; b <<= 1) if (__ballot(f & b)) wf |= b;
 	if (wf && lane_id() == 0 && (*(volatile uint32_t *)flags & wf) != wf) atomicOr(flags, wf);
 }
 
@@ -133,6 +135,18 @@ __global__ void k_merge(const uint64_t *kk, const double *kv, const uint8_t *hea
 	val[o] = acc;
 }
 
+// An operand with nothing to drop and nothing to merge: the sorted tuples are the consolidated ones.
+__global__ void k_gather_sorted(const uint64_t *keys, const uint32_t *perm, const double *val, size_t n, int minor_bits,
+	int32_t *row, int32_t *col, double *oval)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t key = keys[i];
+	row[i] = (int32_t)(key >> minor_bits);
+	col[i] = (int32_t)(key & ((uint64_t(1) << minor_bits) - 1));
+	oval[i] = val[perm[i]];
+}
+
 static unsigned grid_for(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 template <class T>
@@ -197,14 +211,24 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	uint32_t *pay0 = c->arena.get<uint32_t>(n), *pay1 = c->arena.get<uint32_t>(n);
 	k_build_keys<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(major, minor, n, mb, keys0);
 	SPS_LAUNCH_CHECK();
-	// An operand that is in (minor, major) order -- a matrix kept sorted by rows and used with 'T', cfg5's R -- needs the stable
-	// passes over the MAJOR digits only: an LSD sort that skips the low digits leaves ties in input order, which is the minor
-	// order already (Galerkin 256^3, R^T: 3 passes instead of 6).
+	// An operand that is STRICTLY in (minor, major) order -- a matrix kept sorted by rows and used with 'T', cfg5's R -- needs
+	// the stable passes over the MAJOR digits only: an LSD sort that skips the low digits leaves ties in input order, which is
+	// the minor order already (Galerkin 256^3, R^T: 3 passes instead of 6).  Strictly: no two tuples share their indices, so
+	// with no value to drop either the sorted tuples ARE the consolidated operand (no flag / compact / merge passes).
 	const int low_bit = (f & 4u) ? 0 : mb;
 	int where = radix_sort_pairs(c, keys0, pay0, keys1, pay1, n, mb + Mb, low_bit);
 	uint64_t *ks = where ? keys1 : keys0;
 	uint32_t *ps = where ? pay1 : pay0;
 	uint64_t *kk = where ? keys0 : keys1;      // the other key buffer is free now
+	if (!(f & 4u) && !(f & 8u)) {
+		out->row = c->arena.get<int32_t>(n);
+		out->col = c->arena.get<int32_t>(n);
+		out->val = c->arena.get<double>(n);
+		k_gather_sorted<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(ks, ps, dv, n, mb, out->row, out->col, out->val);
+		SPS_LAUNCH_CHECK();
+		out->nnz = (uint32_t)n;
+		return;
+	}
 
 	double *sval = c->arena.get<double>(n);
 	uint8_t *keep = c->arena.get<uint8_t>(n);

@@ -888,24 +888,32 @@ def test_presorted_operands(ctx):
     _check(_dev(ctx, A, B), want)
 
 
+@pytest.mark.parametrize("dups,zeros", [(True, True), (False, True), (False, False)])
 @pytest.mark.parametrize("policy", [0, 1, 2])
-def test_row_sorted_operand_used_transposed(ctx, policy):
-    """An operand stored in (row, column) order -- with duplicate tuples, explicit zeros and NaNs, not declared sorted -- and
-    used with 'T': its consolidation by columns sorts on the major digits only (the LSD passes over the low digits are
-    skipped: the ties stay in input order, which is the minor order already).  Both as A and as B, every duplicate
-    policy, against the oracle; and the stand-alone consolidate by {1, 0} of the same tuples."""
+def test_row_sorted_operand_used_transposed(ctx, policy, dups, zeros):
+    """An operand stored in (row, column) order, not declared sorted, and used with 'T'.  Strictly ascending: its
+    consolidation by columns sorts on the major digits only (the LSD passes over the low digits are skipped: ties stay in
+    input order, which is the minor order already) and, with no value to drop, the sorted tuples are the result; with
+    explicit zeros the flag / compact / merge passes follow; with duplicate tuples the full sort.  Both as A and as B,
+    every duplicate policy, against the oracle; and the stand-alone consolidate by {1, 0} of the same tuples."""
     rng = np.random.default_rng(31 + policy)
     n, m = 3000, 70000
     i0 = np.sort(rng.integers(0, 300, n)).astype(np.int32)                  # rows ascending, many per row
     i1 = rng.integers(0, m, n).astype(np.int32)
     order = np.lexsort((i1, i0))
     i0, i1 = i0[order], i1[order]
-    dup = rng.integers(0, n - 1, 400)
-    i0[dup + 1], i1[dup + 1] = i0[dup], i1[dup]                              # duplicate tuples, adjacent (still in order)
-    order = np.lexsort((i1, i0), )
-    i0, i1 = i0[order], i1[order]
+    if dups:
+        dup = rng.integers(0, n - 1, 400)
+        i0[dup + 1], i1[dup + 1] = i0[dup], i1[dup]                          # duplicate tuples, adjacent (still in order)
+        order = np.lexsort((i1, i0), )
+        i0, i1 = i0[order], i1[order]
+    else:                                                                   # strictly ascending: sorted tuples = consolidated operand
+        keep = np.concatenate([[True], (np.diff(i0) != 0) | (np.diff(i1) != 0)])
+        i0, i1 = i0[keep], i1[keep]
+        n = i0.size
     v = rng.standard_normal(n)
-    v[rng.integers(0, n, 60)] = 0.0
+    if zeros:
+        v[rng.integers(0, n, 60)] = 0.0
     X = orc.Mat(i0, i1, v, (300, m))                                       # sort0 = -1: nothing declared
     Y = _rand_mat(rng, (300, 40), 2000)
     kw = dict(duplicate_policy=policy)
