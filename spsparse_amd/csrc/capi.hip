@@ -19,7 +19,7 @@ using namespace spsamd;
 	catch (const std::bad_alloc &) { (ctx)->last_error = "host allocation failed"; return SPSAMD_ENOMEM; } \
 	catch (const std::exception &e) { (ctx)->last_error = e.what(); return SPSAMD_EINVAL; }
 
-extern "C" const char *spsamd_version(void) { return "spsparse_amd 0.1 (gfx950)"; }
+extern "C" const char *spsamd_version(void) { return "spsparse_amd 0.2 (gfx950)"; }
 
 extern "C" int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream)
 {
