@@ -339,21 +339,49 @@ __global__ void k_rowptr(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t
 
 // The same from the tuples' side: tuple t (and the end, t = n) writes the entries of the rows between its predecessor's row
 // and its own -- one streaming pass over the row indices instead of a binary search per row (cfg3, 8.4e7 tuples in 1.7e7
-// rows: 0.41 -> 0.1 ms).  A thread loops over a GAP of empty rows, so this form is for operands without huge ones.
+// rows: 0.41 -> 0.1 ms).  A short gap of empty rows is filled by its thread; a long one -- the rows before and after a row
+// BLOCK of a sharded product are empty: hundreds of thousands of entries -- by the whole wave (left to one thread such a
+// gap cost 10 ms per call).
 __global__ void k_rowptr_scatter(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t *ptr)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t > n) return;
-	const uint64_t first = t == 0 ? 0 : (uint64_t)(uint32_t)row[t - 1] + 1;       // entries below were written by earlier tuples
-	const uint64_t last = t == n ? nptr : std::min<uint64_t>((uint64_t)(uint32_t)row[t] + 1, nptr);   // [first, last) = rows r with ptr[r] = t
-	for (uint64_t r = first; r < last; ++r) ptr[r] = (uint32_t)t;
+	uint64_t first = 0, last = 0;                                    // [first, last) = rows r with ptr[r] = t
+	if (t > 0 && t < n) {                                           // (the rows up to the first tuple's and after the last one's: k_rowptr_ends)
+		first = (uint64_t)(uint32_t)row[t - 1] + 1;                 // entries below were written by earlier tuples
+		last = std::min<uint64_t>((uint64_t)(uint32_t)row[t] + 1, nptr);
+	}
+	const uint64_t gap = last > first ? last - first : 0;
+	if (gap <= 8) for (uint64_t r = first; r < last; ++r) ptr[r] = (uint32_t)t;
+	uint64_t big = __ballot(gap > 8);
+	while (big) {                                                   // uniform
+		const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)big) - 1);
+		big &= big - 1ull;
+		const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(first >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)first, l);
+		const uint64_t e = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(last >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)last, l);
+		const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, l);
+		for (uint64_t r = f + lane_id(); r < e; r += 64) ptr[r] = v;
+	}
+}
+
+// ... and the two ends, one thread per pointer entry: rows up to the first tuple's row point at 0, rows after the last
+// tuple's at n (the two long gaps of a row block).
+__global__ void k_rowptr_ends(const int32_t *row, uint32_t n, uint64_t nptr, uint32_t *ptr)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nptr) return;
+	if (r <= (uint64_t)(uint32_t)row[0]) ptr[r] = 0u;
+	else if (r > (uint64_t)(uint32_t)row[n - 1]) ptr[r] = n;
 }
 
 uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra)
 {
 	uint64_t nptr = m.nrow + 1 + extra;
 	uint32_t *ptr = c->arena.get<uint32_t>(nptr);
-	if (nptr <= 8ull * m.nnz + 1024) k_rowptr_scatter<<<dim3(grid_for((size_t)m.nnz + 1)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+	if (m.nnz && nptr <= 8ull * m.nnz + 1024) {
+		k_rowptr_ends<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+		SPS_LAUNCH_CHECK();
+		k_rowptr_scatter<<<dim3(grid_for((size_t)m.nnz + 1)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
+	}
 	else k_rowptr<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);     // (mostly empty rows: a search per pointer entry)
 	SPS_LAUNCH_CHECK();
 	return ptr;

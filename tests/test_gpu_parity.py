@@ -1193,6 +1193,40 @@ def test_cfg5_galerkin256_full_size_properties(ctx):
     assert np.all(np.diff(ci * nc ** 3 + cj) > 0)         # ascending (i, j), each once
 
 
+def test_row_block_of_a_sharded_product_costs_its_share(ctx):
+    """A row BLOCK of A times the whole of B (what one rank of a sharded product runs): the rows before and after the block
+    are empty.  The dense row pointer once filled such a gap from ONE thread (10 ms per call at scale 20: the 8-block
+    rehearsal fell from 5.7x to 3.0x); the device time of a 1/8 block must stay well under half of the whole product's,
+    and its digest must add up with the other blocks' to the whole."""
+    import torch
+    from spsparse_amd import capi
+    scale = 19
+    n, ne = 1 << scale, 16 << scale
+    A, keep = _device_operand(ctx, lambda *p: ctx.gen_rmat(scale, 3, 0, ne, *p), ne, (n, n))
+    r = ctx.consolidate(A, 0)
+    m = int(r.nnz)
+    c0 = torch.empty(m, dtype=torch.int32, device="cuda:0"); c1 = torch.empty_like(c0); cv = torch.empty(m, dtype=torch.float64, device="cuda:0")
+    ctx.memcpy(c0.data_ptr(), r.idx0, m * 4); ctx.memcpy(c1.data_ptr(), r.idx1, m * 4); ctx.memcpy(cv.data_ptr(), r.val, m * 8)
+    torch.cuda.synchronize()
+    B = capi.device_coo(c0.data_ptr(), c1.data_ptr(), cv.data_ptr(), m, (n, n), sort0=0)
+    whole = min((ctx.multiply(B, B, sink=capi.SINK_DIGEST) for _ in range(3)), key=lambda x: x.ms_total)
+    nnz = hsh = 0
+    worst = 0.0
+    for lo, hi in ((0, n // 64), (n // 64, n // 8), (n // 8, n // 2), (n // 2, n - 1000), (n - 1000, n)):
+        sel = (c0 >= lo) & (c0 < hi)
+        a0, a1, av = c0[sel].contiguous(), c1[sel].contiguous(), cv[sel].contiguous()
+        blk = capi.device_coo(a0.data_ptr(), a1.data_ptr(), av.data_ptr(), a0.numel(), (n, n), sort0=0)
+        d = min((ctx.multiply(blk, B, sink=capi.SINK_DIGEST) for _ in range(3)), key=lambda x: x.ms_total)
+        nnz += d.nnz; hsh = (hsh + d.hash) % (1 << 64)
+        # a block's time: its share of the products plus a fixed part (B's indices) that the whole product pays once
+        share = d.products / max(1, whole.products)
+        worst = max(worst, d.ms_total - share * whole.ms_total)
+    assert nnz == whole.nnz and hsh == whole.hash
+    print("row-block fixed part: %.2f ms of a whole %.2f ms" % (worst, whole.ms_total))
+    assert worst < 0.2 * whole.ms_total, (worst, whole.ms_total)
+    del keep
+
+
 def test_cfg4_rmat23_single_gpu_properties(ctx):
     """BASELINE cfg4 on ONE GPU ("the same input must also run on 1 GPU"): R-MAT scale-23
     A*A, 134M raw tuples, P ~ 3.7e11, digest + row statistics.  Too large for the oracle: every row
