@@ -143,7 +143,7 @@ void fill_zero(spsamd_ctx *c, void *p, size_t bytes)
 // ------------------------------------------------------------------ scan
 
 constexpr int SCAN_NT = 256;
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ITEMS = 4;     // consecutive elements per thread (8 and 16 measured slower: the strided reads coalesce worse; 2 the same)
 constexpr int SCAN_TILE = SCAN_NT * SCAN_ITEMS;
 
 template <class TIn, class TOut>
