@@ -108,6 +108,8 @@ struct spsamd_ctx {
 	std::string last_error;
 	hipEvent_t ev[10] = {};
 	hipEvent_t ev2[3] = {};                  // around the tile launches of the heavy rows
+	hipStream_t side = nullptr;              // second stream: the window-major copy of B is built on it beside the rest of the symbolic phase
+	hipEvent_t ev_side[2] = {};              // [0] main -> side (inputs ready), [1] side -> main (copy built)
 	int num_cu = 256;
 	void *host_staging(size_t bytes);
 };

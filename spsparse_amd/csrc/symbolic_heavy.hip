@@ -384,6 +384,21 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * nwp);
 	k_bwin_build<<<dim3((unsigned)c->num_cu * 32u), dim3(256), 0, st>>>(B.col, bptr, nrowb, hv.nwin, nwp, wshift, hv.bwin, wcnt);
 	SPS_LAUNCH_CHECK();
+	// The window-major copy of B needs only the index just built: it goes to the context's side stream now, beside the
+	// histograms, the cell grouping and their host round trips (a product with heavy rows almost always has dense cells; where
+	// it has none the copy was built for nothing).  The main stream waits for it before the numeric phase (SideJoin).
+	struct SideJoin {
+		spsamd_ctx *c; bool on = false;
+		~SideJoin() { if (on) { (void)hipEventRecord(c->ev_side[1], c->side); (void)hipStreamWaitEvent(c->stream, c->ev_side[1], 0); } }
+	} side_join{c};
+	if (!c->tune.no_wmajor) {
+		SPS_HIP(hipEventRecord(c->ev_side[0], st));
+		SPS_HIP(hipStreamWaitEvent(c->side, c->ev_side[0], 0));
+		side_join.on = true;                                        // from here on the main stream must wait for the side stream, whatever happens
+		c->stream = c->side;                                        // (the helpers launch on c->stream)
+		try { heavy_window_major(c, hv, B, wshift); } catch (...) { c->stream = st; throw; }
+		c->stream = st;
+	}
 	uint32_t *hubcount = c->arena.get<uint32_t>(1);
 	uint32_t *hublist = c->arena.get<uint32_t>(WH_HUB_MAX);
 	fill_zero(c, hubcount, sizeof(uint32_t));
@@ -479,7 +494,6 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	for (int k = 0; k < NCLS; ++k) hv.ncell[k] = hw[k];
 	hv.ntcell = hw[NCLS]; hv.ntile = hw[NCLS + 1]; hv.ntcell2 = hw[NCLS + 2]; hv.ntile2 = hw[NCLS + 3];
 	for (int k = 0; k < NCLS + 2; ++k) hv.clsprod[k] = (unsigned long long)hw[NCLS + 4 + 2 * k] | ((unsigned long long)hw[NCLS + 5 + 2 * k] << 32);
-	if ((hv.ncell[CLS_DENSE] || hv.ntile2) && !c->tune.no_wmajor) heavy_window_major(c, hv, B, wshift);
 }
 
 // Emit the cells (needs segbase for the COO sink) and order the dense ones by descending products.
