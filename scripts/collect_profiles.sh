@@ -18,6 +18,8 @@ trace cfg3 --workload poisson --steps 5 --warmup 1 &&
 trace cfg3_coo --workload poisson --sink coo --steps 5 --warmup 1 &&
 trace cfg5 --workload galerkin --steps 5 --warmup 1 &&
 trace cfg4 --scale 23 --steps 2 --warmup 1 --no-cpu-baseline &&
+PYTHONPATH=$R rocprofv3 --kernel-trace --stats -d $OUT/trace_block -o block -- python3 $R/scripts/prof_block.py > $OUT/block.log 2> $OUT/err_block.txt &&
+echo "trace block done" &&
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY"; do
 	tag=$(echo $pass | cut -d' ' -f1)
 	rocprofv3 --pmc $pass -d $OUT/pmc_$tag -o cfg2 --output-format csv -- $B --steps 2 --warmup 1 --no-other-configs --no-cpu-baseline > $OUT/bench_pmc_$tag.json 2> $OUT/err_pmc_$tag.txt || exit 1
