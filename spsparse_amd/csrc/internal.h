@@ -87,6 +87,7 @@ struct Tuning {
 	int long_cap = 0;            // 0: cell_cap; grouping target of the hash cells of rows too long for tiles (<= 4096)
 	int long_dense_min = 0;      // 0: default (1024 with 8192-column windows, else dense_min); dense threshold of the rows too long for tiles
 	int direct_min = 0;          // 0: default; products above which one window of a tile row becomes a direct cell (>= dense_min: never)
+	int trace = 0;               // 1: the symbolic phase prints its choices to stderr
 	int index_budget_mb = 0;     // 0: 80 % of the free device memory; cap (MB) of the heavy rows' window indices, beyond which the product goes by column blocks
 #ifdef SPSAMD_ABLATIONS
 	int dbg = 0;

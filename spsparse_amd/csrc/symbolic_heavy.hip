@@ -475,7 +475,7 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 		const unsigned long long cells_hash = (unsigned long long)hw[0] | ((unsigned long long)hw[1] << 32);
 		const unsigned long long cells_bm = (unsigned long long)hw[2] | ((unsigned long long)hw[3] << 32);
 		hv.alt_cells = nullptr;
-		if (getenv("SPSAMD_TRACE")) fprintf(stderr, "tile cells: bitmap %llu hash %llu\n", cells_bm, cells_hash);
+		if (c->tune.trace) fprintf(stderr, "tile cells: bitmap %llu hash %llu\n", cells_bm, cells_hash);
 		if (cells_bm * 100u > cells_hash * 140u) { set_scheme(2); count_pass(); }
 	} else count_pass();
 	// every per-row counter of the grouping scanned in one batch, every total read back in one round trip
