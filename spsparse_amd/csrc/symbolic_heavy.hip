@@ -62,23 +62,21 @@ __global__ __launch_bounds__(256) void k_bwin_build(const int32_t *bcol, const u
 // with a CSR row pointer per window: wptr[w * nrowb + k] .. [+1].  The working set of the
 // workgroups that are on window w is then |B_w| * 12 bytes plus a 4 * nrowb byte pointer slice,
 // and a row's pass over its A tuples (ascending k) moves forward through both.
-__global__ __launch_bounds__(256) void k_wm_counts(const uint32_t *bwin, uint32_t nrowb, uint32_t nwin, uint32_t nwin1, uint16_t *cnt)
+__global__ __launch_bounds__(256) void k_wm_counts(const uint16_t *wcnt, uint32_t nrowb, uint32_t nwin, uint32_t nwp, uint16_t *cnt)
 {
-	__shared__ uint32_t tile[64][65];
+	// transposes the 16-bit counts of k_bwin_build (row-major, nwp per row) into window-major order through LDS (reading the
+	// counts instead of differencing the 32-bit index halves the bytes read)
+	__shared__ uint16_t tile[64][66];
 	const uint32_t k0 = blockIdx.x * 64u, w0 = blockIdx.y * 64u;
 	const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
 	for (uint32_t ky = ty; ky < 64; ky += 4) {
 		const uint32_t k = k0 + ky;
-		if (k < nrowb) {
-			const uint32_t *row = bwin + (uint64_t)k * nwin1;
-			if (w0 + tx < nwin1) tile[ky][tx] = row[w0 + tx];
-			if (tx == 0 && w0 + 64 < nwin1) tile[ky][64] = row[w0 + 64];
-		}
+		if (k < nrowb && w0 + tx < nwin) tile[ky][tx] = wcnt[(uint64_t)k * nwp + w0 + tx];
 	}
 	__syncthreads();
 	for (uint32_t wy = ty; wy < 64; wy += 4) {
 		const uint32_t w = w0 + wy, k = k0 + tx;
-		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = (uint16_t)(tile[tx][wy + 1] - tile[tx][wy]);   // <= W tuples of one row in one window
+		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = tile[tx][wy];
 	}
 }
 
@@ -327,13 +325,13 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 	if (i < n) dst[i] = src[perm[i]];
 }
 
-static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift)
+static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift, const uint16_t *wcnt, uint32_t nwp)
 {
 	hipStream_t st = c->stream;
 	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
 	uint16_t *cnt = c->arena.get<uint16_t>(total);
 	hv.wptr = c->arena.get<uint32_t>(total + 1);
-	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(hv.bwin, (uint32_t)nrowb, hv.nwin, hv.nwin1, cnt);
+	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(wcnt, (uint32_t)nrowb, hv.nwin, nwp, cnt);
 	SPS_LAUNCH_CHECK();
 	scan_exclusive_u16_u32(c, cnt, hv.wptr, total);
 	hv.btw = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);
@@ -396,7 +394,7 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 		SPS_HIP(hipStreamWaitEvent(c->side, c->ev_side[0], 0));
 		side_join.on = true;                                        // from here on the main stream must wait for the side stream, whatever happens
 		c->stream = c->side;                                        // (the helpers launch on c->stream)
-		try { heavy_window_major(c, hv, B, wshift); } catch (...) { c->stream = st; throw; }
+		try { heavy_window_major(c, hv, B, wshift, wcnt, nwp); } catch (...) { c->stream = st; throw; }
 		c->stream = st;
 	}
 	uint32_t *hubcount = c->arena.get<uint32_t>(1);
