@@ -102,7 +102,7 @@ typedef struct {
 #define SPSAMD_SINK_DIGEST    2   /* count + sum + index hash only (ScalarAccumulator analogue, accum.hpp:158-167) */
 
 /* sink flags */
-#define SPSAMD_SINK_ROWSTATS  1   /* DIGEST: also fill row_nnz / row_sum (length = rows of op(A)) */
+#define SPSAMD_SINK_ROWSTATS  1   /* DIGEST: also fill row_nnz / row_sum / row_hash (length = rows of op(A)) */
 #define SPSAMD_SINK_PERMUTE   4   /* COO, matrix result: emit (j, i, v) -- idx0 holds the column, idx1 the row, shape
                                    * swapped (PermuteAccum with perm {1,0}, accum.hpp:73-101; the tuples stay in
                                    * the order of C's rows, i.e. column-major for the permuted array) */
@@ -156,6 +156,7 @@ typedef struct {
 	 * (off by default: 0); the rest of ms_heavy - ms_dense is the windowed k_hash of the longer rows */
 	float ms_tiles, ms_direct;
 	uint64_t products_tiles, products_direct;
+	const uint64_t *row_hash;     /* DIGEST|ROWSTATS: per row the sum of mix64(i, j) over its tuples (device pointer) */
 } spsamd_result;
 
 /* ---- context ---- */

@@ -32,6 +32,11 @@ class _Vec(C.Structure):
                 ("shape0", C.c_size_t), ("sort0", C.c_int)]
 
 
+class _DigestOut(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("hash", C.c_uint64), ("products", C.c_uint64), ("nnz_a", C.c_uint64),
+                ("nnz_b", C.c_uint64), ("sum", C.c_double), ("row_nnz", C.c_void_p), ("row_hash", C.c_void_p)]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "spsparse_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -65,6 +70,8 @@ def lib():
         L.orc_multiply_mm_rowwise.argtypes = mm + [C.c_int, C.c_char_p, C.c_size_t]
         L.orc_multiply_mv.argtypes = [C.POINTER(_Coo), C.c_double, C.POINTER(_Vec), C.POINTER(_Mat), C.c_char,
                                       C.POINTER(_Vec), C.POINTER(_Vec), C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.orc_multiply_mm_rowwise_digest.argtypes = [C.POINTER(_DigestOut), C.c_void_p] + mm[1:] + [C.c_int, C.c_char_p, C.c_size_t]
+        L.orc_sorted_permutation_merge.argtypes = L.orc_sorted_permutation.argtypes
         L.orc_mix64.restype = C.c_uint64
         L.orc_mix64.argtypes = [C.c_uint32, C.c_uint32]
         _lib = L
@@ -198,6 +205,65 @@ def multiply(A, B, C_=1.0, scalei=None, tA='.', scalej=None, tB='.', scalek=None
     if rc != 0:
         raise OracleError(msg.value.decode())
     return out
+
+
+class Digest:
+    """Result of multiply_digest: count / hash / sum as the device's digest sink reports them, the scalar
+    products, the consolidated operand sizes, and (rowstats) per-row tuple counts and index hashes."""
+
+    def __init__(self, d, row_nnz, row_hash):
+        self.nnz, self.hash, self.sum = int(d.count), int(d.hash), float(d.sum)
+        self.products, self.nnz_a, self.nnz_b = int(d.products), int(d.nnz_a), int(d.nnz_b)
+        self.row_nnz, self.row_hash = row_nnz, row_hash
+
+
+def host_threads(cap=64):
+    """Threads worth starting on this host: the CPUs this process may run on, less where a cgroup quota says so."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def multiply_digest(A, B, C_=1.0, scalei=None, tA='.', scalej=None, tB='.', scalek=None,
+                    duplicate_policy=ADD, zero_nan=False, nthreads=1, row_mask=None, rowstats=False):
+    """The row-wise checker as a streaming digest (no tuple is stored); row_mask: uint8 per row of op(A),
+    only rows with a non-zero byte are evaluated."""
+    nrow = A.shape[1] if tA == 'T' else A.shape[0]
+    d = _DigestOut()
+    row_nnz = row_hash = None
+    if rowstats:
+        row_nnz, row_hash = np.zeros(nrow, np.int64), np.zeros(nrow, np.uint64)
+        d.row_nnz, d.row_hash = row_nnz.ctypes.data, row_hash.ctypes.data
+    mask = None
+    if row_mask is not None:
+        mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+        assert mask.size == nrow
+    msg = C.create_string_buffer(256)
+    keep = [x._c() if x is not None else None for x in (scalei, A, scalej, B, scalek)]
+    ptr = [None if k is None else C.byref(k) for k in keep]
+    rc = lib().orc_multiply_mm_rowwise_digest(C.byref(d), None if mask is None else mask.ctypes.data, float(C_), ptr[0], ptr[1],
+                                              tA.encode(), ptr[2], ptr[3], tB.encode(), ptr[4], duplicate_policy,
+                                              int(zero_nan), int(nthreads), msg, 256)
+    if rc != 0:
+        raise OracleError(msg.value.decode())
+    return Digest(d, row_nnz, row_hash)
+
+
+def sorted_permutation_merge(idx0, idx1, so0):
+    """orc_sorted_permutation through the merge sort alone (the radix path of large inputs is checked against it)."""
+    idx0 = _i32(idx0)
+    rank = 1 if idx1 is None else 2
+    idx1 = None if idx1 is None else _i32(idx1)
+    perm = np.zeros(idx0.size, dtype=np.uintp)
+    lib().orc_sorted_permutation_merge(rank, idx0.ctypes.data, None if idx1 is None else idx1.ctypes.data,
+                                       idx0.size, so0, perm.ctypes.data)
+    return perm
 
 
 def multiply_mv(A, V, C_=1.0, scalei=None, tA='.', scalej=None, duplicate_policy=ADD, zero_nan=False):

@@ -105,6 +105,46 @@ static void stable_sort_perm(const cmp_ctx *c, size_t *perm, size_t n)
 	free(tmp);
 }
 
+/* Large inputs (the BASELINE-size checks: 1.3e8 tuples at R-MAT scale 23): the same permutation from a
+ * stable LSD radix sort on the key (d[0] << 32 | d[1]) -- any stable sort of the same order gives the
+ * permutation std::stable_sort gives.  Non-negative indices only (returns 0 otherwise: merge sort). */
+#define ORC_RADIX_MIN ((size_t)1 << 16)
+
+static int radix_sort_perm(const cmp_ctx *c, size_t *perm, size_t n)
+{
+	uint64_t *k0 = (uint64_t *)malloc(n * sizeof(uint64_t)), *k1 = (uint64_t *)malloc(n * sizeof(uint64_t));
+	uint32_t *p0 = (uint32_t *)malloc(n * sizeof(uint32_t)), *p1 = (uint32_t *)malloc(n * sizeof(uint32_t));
+	int ok = k0 && k1 && p0 && p1 && n < ((size_t)1 << 32);
+	uint64_t all = 0;
+	for (size_t i = 0; ok && i < n; ++i) {
+		int32_t hi = c->rank == 2 ? c->d[0][i] : 0, lo = c->rank == 2 ? c->d[1][i] : c->d[0][i];
+		if (hi < 0 || lo < 0) { ok = 0; break; }
+		k0[i] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+		p0[i] = (uint32_t)i;
+		all |= k0[i];
+	}
+	if (ok) {
+		size_t *cnt = (size_t *)xmalloc(65536 * sizeof(size_t));
+		for (int shift = 0; shift < 64; shift += 16) {
+			if (((all >> shift) & 0xFFFF) == 0) continue;      /* a digit that is 0 everywhere moves nothing */
+			memset(cnt, 0, 65536 * sizeof(size_t));
+			for (size_t i = 0; i < n; ++i) cnt[(k0[i] >> shift) & 0xFFFF]++;
+			size_t run = 0;
+			for (size_t d = 0; d < 65536; ++d) { size_t t = cnt[d]; cnt[d] = run; run += t; }
+			for (size_t i = 0; i < n; ++i) {
+				size_t o = cnt[(k0[i] >> shift) & 0xFFFF]++;
+				k1[o] = k0[i]; p1[o] = p0[i];
+			}
+			uint64_t *tk = k0; k0 = k1; k1 = tk;
+			uint32_t *tp = p0; p0 = p1; p1 = tp;
+		}
+		free(cnt);
+		for (size_t i = 0; i < n; ++i) perm[i] = p0[i];
+	}
+	free(k0); free(k1); free(p0); free(p1);
+	return ok;
+}
+
 void orc_sorted_permutation(int rank, const int32_t *idx0, const int32_t *idx1,
 	size_t n, int so0, size_t *perm)
 {
@@ -114,7 +154,21 @@ void orc_sorted_permutation(int rank, const int32_t *idx0, const int32_t *idx1,
 	else if (so0 == 0) { c.d[0] = idx0; c.d[1] = idx1; }
 	else { c.d[0] = idx1; c.d[1] = idx0; }
 	for (size_t i = 0; i < n; ++i) perm[i] = i;     /* algorithm.hpp:419-421 */
+	if (n >= ORC_RADIX_MIN && radix_sort_perm(&c, perm, n)) return;
 	stable_sort_perm(&c, perm, n);                  /* algorithm.hpp:424 */
+}
+
+/* the merge sort alone, whatever the size (tests compare the two paths) */
+void orc_sorted_permutation_merge(int rank, const int32_t *idx0, const int32_t *idx1,
+	size_t n, int so0, size_t *perm)
+{
+	cmp_ctx c;
+	c.rank = rank;
+	if (rank == 1) { c.d[0] = idx0; c.d[1] = NULL; }
+	else if (so0 == 0) { c.d[0] = idx0; c.d[1] = idx1; }
+	else { c.d[0] = idx1; c.d[1] = idx0; }
+	for (size_t i = 0; i < n; ++i) perm[i] = i;
+	stable_sort_perm(&c, perm, n);
 }
 
 /* ------------------------------------------------------------------ */
@@ -459,7 +513,11 @@ static int cmp_i32(const void *a, const void *b)
 	return (x > y) - (x < y);
 }
 
-int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
+/* Shared body of the row-wise checker.  dg == NULL: the tuples go to `ret` (rows split statically over the
+ * threads, parts appended in row order).  dg != NULL: streaming digest -- nothing is stored, rows are handed
+ * out dynamically (an un-permuted R-MAT has most of its products in its first rows), and only the rows with
+ * row_mask[i] != 0 are evaluated when a mask is given. */
+static int rowwise_core(orc_coo *ret, orc_digest_out *dg, const uint8_t *row_mask, double C, const orc_vec *scalei,
 	const orc_mat *A, char transpose_A, const orc_vec *scalej,
 	const orc_mat *B, char transpose_B, const orc_vec *scalek,
 	int duplicate_policy, int zero_nan, int nthreads, char *msg, size_t msglen)
@@ -468,8 +526,8 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 	int b0 = transpose_B == 'T' ? 0 : 1, b1 = 1 - b0;
 	size_t ashape[2] = { A->shape0, A->shape1 };
 	size_t bshape[2] = { B->shape0, B->shape1 };
-	ret->shape0 = ashape[a0];
-	ret->shape1 = bshape[b0];
+	if (ret) { ret->shape0 = ashape[a0]; ret->shape1 = bshape[b0]; }
+	if (dg) { dg->count = 0; dg->hash = 0; dg->sum = 0; dg->products = 0; dg->nnz_a = 0; dg->nnz_b = 0; }
 	if (ashape[a1] != bshape[b1]) {
 		set_msg(msg, msglen, "Inner dimensions for A (%ld) and B (%ld) must match!",
 			(long)ashape[a1], (long)bshape[b1]);
@@ -495,11 +553,15 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 	 * own (column-major of op(B)) sort order b0 -- which tuples zero_nan drops depends on that
 	 * sequence (algorithm.hpp:272-275 vs :284-292) -- and THEN put in rows-of-op(B) order by a
 	 * plain stable sort that drops and merges nothing (explicit zeros left by a +x/-x merge
-	 * stay, as they do in the reference's copy). */
+	 * stay, as they do in the reference's copy).  Without zero_nan the sequence does not matter
+	 * (exact zeros are dropped wherever they stand and equal indices merge in insertion order under
+	 * either stable sort), so B is consolidated by rows of op(B) at once. */
 	conmat Ac, Bc, Bref;
 	conmat_build(&Ac, A, a0, duplicate_policy, zero_nan);
-	conmat_build(&Bref, B, b0, duplicate_policy, zero_nan);
-	{
+	if (!zero_nan) {
+		conmat_build(&Bc, B, b1, duplicate_policy, 0);
+	} else {
+		conmat_build(&Bref, B, b0, duplicate_policy, zero_nan);
 		/* Bref: lead = index(b0), minor = index(b1); re-sort by (minor, lead) */
 		size_t nb = Bref.n;
 		size_t *perm = (size_t *)xmalloc((nb ? nb : 1) * sizeof(size_t));
@@ -515,6 +577,7 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 		free(perm); free(t0); free(t1); free(tv);
 		conmat_free(&Bref);
 	}
+	if (dg) { dg->nnz_a = Ac.n; dg->nnz_b = Bc.n; }
 
 	/* row pointer of op(B) over all inner indices */
 	size_t *bptr = (size_t *)xmalloc((ninner + 1) * sizeof(size_t));
@@ -527,8 +590,15 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 	}
 
 	if (nthreads < 1) nthreads = 1;
-	orc_coo *parts = (orc_coo *)xmalloc((size_t)nthreads * sizeof(orc_coo));
-	for (int t = 0; t < nthreads; ++t) orc_coo_init(&parts[t], 2);
+	orc_coo *parts = NULL;
+	if (ret) {
+		parts = (orc_coo *)xmalloc((size_t)nthreads * sizeof(orc_coo));
+		for (int t = 0; t < nthreads; ++t) orc_coo_init(&parts[t], 2);
+	}
+	uint64_t g_count = 0, g_hash = 0, g_prod = 0;
+	double g_sum = 0;
+	size_t next_row = 0;                    /* digest mode: the shared cursor rows are handed out from */
+	const size_t chunk = 16;
 
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nthreads)
@@ -541,62 +611,112 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 		int t = 0, nt = 1;
 #endif
 		if (t < nthreads) {
-			size_t r0 = Ac.nrows * (size_t)t / (size_t)nt;
-			size_t r1 = Ac.nrows * (size_t)(t + 1) / (size_t)nt;
 			double *acc = (double *)xmalloc(ncol * sizeof(double));
 			unsigned char *flag = (unsigned char *)calloc(ncol ? ncol : 1, 1);
 			int32_t *touched = (int32_t *)xmalloc(ncol * sizeof(int32_t));
-			for (size_t ra = r0; ra < r1; ++ra) {
-				int32_t aix = Ac.rowid[ra];
-				double a_scale = 1.0;
-				if (scalei) {
-					if (pi[aix] < 0) continue;      /* absent => row skipped */
-					a_scale = scalei->val[pi[aix]];
+			uint64_t l_count = 0, l_hash = 0, l_prod = 0;
+			double l_sum = 0;
+			size_t r0 = Ac.nrows * (size_t)t / (size_t)nt;
+			size_t r1 = Ac.nrows * (size_t)(t + 1) / (size_t)nt;
+			for (;;) {
+				if (dg) {
+#ifdef _OPENMP
+#pragma omp atomic capture
+#endif
+					{ r0 = next_row; next_row += chunk; }
+					if (r0 >= Ac.nrows) break;
+					r1 = r0 + chunk < Ac.nrows ? r0 + chunk : Ac.nrows;
 				}
-				if (orc_isnone(a_scale, 0)) continue;
-				size_t nt_ = 0;
-				for (size_t e = Ac.beg[ra]; e < Ac.beg[ra + 1]; ++e) {   /* ascending k */
-					int32_t k = Ac.minor[e];
-					double a = Ac.val[e];
-					if (scalej) {
-						if (pj[k] < 0) continue;    /* absent => term dropped */
-						a = a * scalej->val[pj[k]]; /* (a*s)*b, multiply_sparse.hpp:228 */
+				for (size_t ra = r0; ra < r1; ++ra) {
+					int32_t aix = Ac.rowid[ra];
+					if (row_mask && !row_mask[aix]) continue;
+					double a_scale = 1.0;
+					if (scalei) {
+						if (pi[aix] < 0) continue;      /* absent => row skipped */
+						a_scale = scalei->val[pi[aix]];
 					}
-					for (size_t f = bptr[k]; f < bptr[k + 1]; ++f) {
-						int32_t j = Bc.minor[f];
-						if (!flag[j]) { flag[j] = 1; touched[nt_++] = j; acc[j] = 0; }
-						acc[j] += a * Bc.val[f];
+					if (orc_isnone(a_scale, 0)) continue;
+					size_t nt_ = 0;
+					for (size_t e = Ac.beg[ra]; e < Ac.beg[ra + 1]; ++e) {   /* ascending k */
+						int32_t k = Ac.minor[e];
+						double a = Ac.val[e];
+						if (scalej) {
+							if (pj[k] < 0) continue;    /* absent => term dropped */
+							a = a * scalej->val[pj[k]]; /* (a*s)*b, multiply_sparse.hpp:228 */
+						}
+						l_prod += (uint64_t)(bptr[k + 1] - bptr[k]);
+						for (size_t f = bptr[k]; f < bptr[k + 1]; ++f) {
+							int32_t j = Bc.minor[f];
+							if (!flag[j]) { flag[j] = 1; touched[nt_++] = j; acc[j] = 0; }
+							acc[j] += a * Bc.val[f];
+						}
+					}
+					if (!dg) qsort(touched, nt_, sizeof(int32_t), cmp_i32);
+					uint64_t r_count = 0, r_hash = 0;
+					for (size_t q = 0; q < nt_; ++q) {
+						int32_t j = touched[q];
+						double sum = acc[j];
+						flag[j] = 0;
+						double b_scale = 1.0;
+						if (scalek) {
+							if (pk[j] < 0) continue;
+							b_scale = scalek->val[pk[j]];
+						}
+						if (orc_isnone(b_scale, 0)) continue;
+						if (orc_isnone(sum, 0)) continue;            /* multiply_sparse.hpp:238 */
+						double v = sum * C * a_scale * b_scale;     /* :242 */
+						if (dg) { ++r_count; r_hash += orc_mix64((uint32_t)aix, (uint32_t)j); l_sum += v; }
+						else coo_add(&parts[t], aix, j, v);
+					}
+					if (dg) {
+						l_count += r_count; l_hash += r_hash;
+						if (dg->row_nnz) dg->row_nnz[aix] = (int64_t)r_count;     /* one writer per row */
+						if (dg->row_hash) dg->row_hash[aix] = r_hash;
 					}
 				}
-				qsort(touched, nt_, sizeof(int32_t), cmp_i32);
-				for (size_t q = 0; q < nt_; ++q) {
-					int32_t j = touched[q];
-					double sum = acc[j];
-					flag[j] = 0;
-					double b_scale = 1.0;
-					if (scalek) {
-						if (pk[j] < 0) continue;
-						b_scale = scalek->val[pk[j]];
-					}
-					if (orc_isnone(b_scale, 0)) continue;
-					if (!orc_isnone(sum, 0))
-						coo_add(&parts[t], aix, j, sum * C * a_scale * b_scale);
-				}
+				if (!dg) break;
 			}
 			free(acc); free(flag); free(touched);
+			if (dg) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+				{ g_count += l_count; g_hash += l_hash; g_sum += l_sum; g_prod += l_prod; }
+			}
 		}
 	}
-	for (int t = 0; t < nthreads; ++t) {
-		for (size_t q = 0; q < parts[t].n; ++q)
-			coo_add(ret, parts[t].i[q], parts[t].j[q], parts[t].v[q]);
-		orc_coo_free(&parts[t]);
+	if (ret) {
+		for (int t = 0; t < nthreads; ++t) {
+			for (size_t q = 0; q < parts[t].n; ++q)
+				coo_add(ret, parts[t].i[q], parts[t].j[q], parts[t].v[q]);
+			orc_coo_free(&parts[t]);
+		}
+		free(parts);
 	}
-	free(parts);
+	if (dg) { dg->count = g_count; dg->hash = g_hash; dg->sum = g_sum; dg->products = g_prod; }
 	free(bptr);
 	free(pi); free(pj); free(pk);
 	conmat_free(&Ac);
 	conmat_free(&Bc);
 	return 0;
+}
+
+int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
+	const orc_mat *A, char transpose_A, const orc_vec *scalej,
+	const orc_mat *B, char transpose_B, const orc_vec *scalek,
+	int duplicate_policy, int zero_nan, int nthreads, char *msg, size_t msglen)
+{
+	return rowwise_core(ret, NULL, NULL, C, scalei, A, transpose_A, scalej, B, transpose_B, scalek,
+		duplicate_policy, zero_nan, nthreads, msg, msglen);
+}
+
+int orc_multiply_mm_rowwise_digest(orc_digest_out *out, const uint8_t *row_mask, double C, const orc_vec *scalei,
+	const orc_mat *A, char transpose_A, const orc_vec *scalej,
+	const orc_mat *B, char transpose_B, const orc_vec *scalek,
+	int duplicate_policy, int zero_nan, int nthreads, char *msg, size_t msglen)
+{
+	return rowwise_core(NULL, out, row_mask, C, scalei, A, transpose_A, scalej, B, transpose_B, scalek,
+		duplicate_policy, zero_nan, nthreads, msg, msglen);
 }
 
 /* ------------------------------------------------------------------ */

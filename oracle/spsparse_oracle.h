@@ -102,6 +102,29 @@ int orc_multiply_mm_rowwise(orc_coo *ret, double C, const orc_vec *scalei,
 	const orc_mat *B, char transpose_B, const orc_vec *scalek,
 	int duplicate_policy, int zero_nan, int nthreads, char *msg, size_t msglen);
 
+/* The same checker as a STREAMING DIGEST (nothing is stored: BASELINE cfg2's product has 1e10 tuples): count,
+ * sum of the emitted values, sum of mix64(i, j) mod 2^64 -- the figures the device's digest sink reports -- the
+ * number of scalar products, and optionally per output row the tuple count and the row's own index hash
+ * (arrays of rows(op(A)) entries, zeroed by the caller; only evaluated rows are written).  Rows are handed to
+ * the threads dynamically.  row_mask (rows(op(A)) bytes) or NULL: evaluate only the rows whose byte is non-zero
+ * (a sample of a product too large to evaluate whole).  What it restates: the per-cell test of
+ * tests/test_multiply_sparse.cpp:119-128 at sizes where the cells cannot be held. */
+typedef struct {
+	uint64_t count, hash, products, nnz_a, nnz_b;
+	double sum;
+	int64_t *row_nnz;       /* in: NULL or rows(op(A)) entries */
+	uint64_t *row_hash;     /* in: NULL or rows(op(A)) entries */
+} orc_digest_out;
+int orc_multiply_mm_rowwise_digest(orc_digest_out *out, const uint8_t *row_mask, double C, const orc_vec *scalei,
+	const orc_mat *A, char transpose_A, const orc_vec *scalej,
+	const orc_mat *B, char transpose_B, const orc_vec *scalek,
+	int duplicate_policy, int zero_nan, int nthreads, char *msg, size_t msglen);
+
+/* orc_sorted_permutation through the merge sort alone (large inputs otherwise take a stable LSD radix sort
+ * that yields the same permutation; tests compare the two). */
+void orc_sorted_permutation_merge(int rank, const int32_t *idx0, const int32_t *idx1,
+	size_t n, int so0, size_t *perm);
+
 /* multiply_sparse.hpp:281-365 (matrix x sparse vector). */
 int orc_multiply_mv(orc_coo *ret, double C, const orc_vec *scalei,
 	const orc_mat *A, char transpose_A, const orc_vec *scalej,

@@ -54,7 +54,8 @@ class Result(C.Structure):
                 ("rows_light", C.c_uint64), ("rows_mid", C.c_uint64), ("rows_heavy", C.c_uint64),
                 ("products_light", C.c_uint64), ("products_mid", C.c_uint64), ("products_heavy", C.c_uint64),
                 ("tuples_light", C.c_uint64), ("tuples_mid", C.c_uint64), ("tuples_heavy", C.c_uint64),
-                ("ms_tiles", C.c_float), ("ms_direct", C.c_float), ("products_tiles", C.c_uint64), ("products_direct", C.c_uint64)]
+                ("ms_tiles", C.c_float), ("ms_direct", C.c_float), ("products_tiles", C.c_uint64), ("products_direct", C.c_uint64),
+                ("row_hash", C.c_void_p)]
 
 
 class DistStats(C.Structure):

@@ -78,7 +78,7 @@ extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
 	if (c->side) (void)hipStreamSynchronize(c->side);
 	c->arena.release();
 	c->out[0].release(); c->out[1].release();
-	c->rowstat_n.release(); c->rowstat_s.release();
+	c->rowstat_n.release(); c->rowstat_s.release(); c->rowstat_h.release();
 	if (c->pinned) (void)hipHostFree(c->pinned);
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : c->ev2) if (e) (void)hipEventDestroy(e);

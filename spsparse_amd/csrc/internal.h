@@ -103,7 +103,7 @@ struct spsamd_ctx {
 	spsamd::Arena arena;
 	spsamd::OutSet out[2];                   // SINK_COO results (see OutSet)
 	int cur_out = 0;
-	spsamd::DevBuf rowstat_n, rowstat_s;     // DIGEST row statistics
+	spsamd::DevBuf rowstat_n, rowstat_s, rowstat_h;     // DIGEST row statistics
 	void *pinned = nullptr;                  // host staging for small readbacks / fetch
 	size_t pinned_cap = 0;
 	std::string last_error;

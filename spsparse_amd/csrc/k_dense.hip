@@ -311,6 +311,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		X0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(X0 >> 32)) << 32) |
 			(unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)X0);
 		double r_sum = 0;
+		unsigned long long r_hash = 0;
 #pragma unroll
 		for (int gi = 0; gi < GPW; ++gi) {
 			int grp = wv * GPW + gi;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			if (MODE == MODE_DIGEST) {
 				unsigned long long h = X0 + laneK;
 				h ^= h >> 29;
-				d_hash += ok ? h : 0ull;
+				r_hash += ok ? h : 0ull;
 				if (plain && !PAT) r_sum += x;                          // (a slot that is not emitted holds +-0)
 				else r_sum += ok ? x : 0.0;
 				X0 += 64ull * MIXK;
@@ -339,9 +340,11 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		if (MODE == MODE_DIGEST) {
 			if (lane == 0) d_cnt += wcount;
 			d_sum += r_sum;
+			d_hash += r_hash;
 			if (sk.row_nnz) {
 				double rs = wave_reduce_sum(r_sum);
-				if (lane == 0 && wcount) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], (unsigned long long)wcount); atomicAdd(&sk.row_sum[rowid], rs); }
+				r_hash = wave_reduce_sum(r_hash);
+				if (lane == 0 && wcount) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], (unsigned long long)wcount); atomicAdd(&sk.row_sum[rowid], rs); atomicAdd(&sk.row_hash[rowid], r_hash); }
 			}
 		} else {
 			if (lane == 0) s_wcnt[wv] = wcount;

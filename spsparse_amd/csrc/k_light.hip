@@ -116,9 +116,10 @@ __global__ __launch_bounds__(256, 8) void k_light(const uint32_t *binrows, uint3
 		if (sk.row_nnz) {
 			// one wave-group owns the row: reduce inside the S lanes, plain store
 			double rs = vs;
+			unsigned long long rh = hash;
 #pragma unroll
-			for (int d = S / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d, 64);
-			if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; }
+			for (int d = S / 2; d >= 1; d >>= 1) { rs += __shfl_xor(rs, d, 64); rh += __shfl_xor(rh, d, 64); }
+			if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; sk.row_hash[rowid] = rh; }
 		}
 		d_cnt += cnt; d_hash += hash; d_sum += vs;
 	}
@@ -292,9 +293,10 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		} else {
 			if (sk.row_nnz) {
 				double rs = out ? value : 0.0;
+				unsigned long long rh = out ? mix64((uint32_t)rowid, mycol) : 0ull;
 #pragma unroll
-				for (int d = S / 2; d >= 1; d >>= 1) rs += __shfl_xor(rs, d, 64);
-				if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; }
+				for (int d = S / 2; d >= 1; d >>= 1) { rs += __shfl_xor(rs, d, 64); rh += __shfl_xor(rh, d, 64); }
+				if (has_row && s == 0) { sk.row_nnz[rowid] = (long long)__popcll(gmask); sk.row_sum[rowid] = rs; sk.row_hash[rowid] = rh; }
 			}
 			if (out) { ++d_cnt; d_hash += mix64((uint32_t)rowid, mycol); d_sum += value; }
 		}

@@ -453,11 +453,11 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 				if (mine) { uint4 *z = reinterpret_cast<uint4 *>(&bm[tid * WPT]); z[0] = make_uint4(0, 0, 0, 0); z[1] = make_uint4(0, 0, 0, 0); }
 			}
 			if constexpr (MODE == MODE_DIGEST) {
-				unsigned long long cnt = 0; double vs = 0;
+				unsigned long long cnt = 0, rh = 0; double vs = 0;
 				auto note = [&](uint32_t rel, double v) {
 					const int32_t col = (int32_t)(colbase + rel);
 					const bool ok = plain ? v != 0 : emit_value(ep, a_scale, col, v, &v);
-					if (ok) { ++cnt; d_hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+					if (ok) { ++cnt; rh += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
 				};
 				if constexpr (!PAT) {
 					unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
@@ -483,10 +483,11 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 						if (valid) note(rel, v);
 					}
 				}
-				d_cnt += cnt; d_sum += vs;
+				d_cnt += cnt; d_sum += vs; d_hash += rh;
 				if (sk.row_nnz) {
 					const unsigned long long rc = wave_reduce_sum(cnt); const double rs = wave_reduce_sum(vs);
-					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+					rh = wave_reduce_sum(rh);
+					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); atomicAdd(&sk.row_hash[rowid], rh); }
 				}
 			} else if constexpr (MODE == MODE_COUNT) {
 				// scalek present: count the allowed columns (every thread walks its own words: no values were accumulated)
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 			// of a step are in flight together (a dump slot is exchanged like any other: its answer is not looked at)
 			unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
 			uint32_t mycount = 0; double mysum = 0.0;
+			unsigned long long myhash = 0;
 #pragma unroll
 			for (int st = 0; st < MAXST; ++st) {
 				if ((uint32_t)st * NW + wv < nblk) {                        // wave-uniform
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 							else own = emit_value(ep, a_scale, col, v, &v);
 						}
 						if constexpr (MODE == MODE_DIGEST) {
-							if (own) { ++mycount; d_hash += mix64((uint32_t)rowid, wbase + slot); mysum += v; }
+							if (own) { ++mycount; myhash += mix64((uint32_t)rowid, wbase + slot); mysum += v; }
 						} else if constexpr (MODE == MODE_COUNT) {
 							if (own) ++mycount;
 						} else {
@@ -726,10 +728,11 @@ __global__ __launch_bounds__(NT, 4) void k_direct_tiles(const Tile *tiles, uint3
 				}
 			}
 			if constexpr (MODE == MODE_DIGEST) {
-				d_cnt += mycount; d_sum += mysum;
+				d_cnt += mycount; d_sum += mysum; d_hash += myhash;
 				if (sk.row_nnz) {
 					const unsigned long long rc = wave_reduce_sum((unsigned long long)mycount); const double rs = wave_reduce_sum(mysum);
-					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+					myhash = wave_reduce_sum(myhash);
+					if (lane == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); atomicAdd(&sk.row_hash[rowid], myhash); }
 				}
 				lds_barrier();                                      // claims done before the next cell accumulates
 			} else if constexpr (MODE == MODE_COUNT) {

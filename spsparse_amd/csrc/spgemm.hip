@@ -276,15 +276,16 @@ __global__ void k_col_compact(const int32_t *row, const int32_t *col, const doub
 }
 
 __global__ void k_block_digest(const int32_t *i, const int32_t *j, const double *v, uint64_t n, uint32_t c0, DigestSlot *slots,
-	long long *row_nnz, double *row_sum)
+	long long *row_nnz, double *row_sum, unsigned long long *row_hash)
 {
 	__shared__ unsigned long long s_u64[2 * 4];
 	__shared__ double s_f64[4];
 	unsigned long long cnt = 0, hash = 0; double sum = 0;
 	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t jj = (uint32_t)j[t] + c0;
-		++cnt; hash += mix64((uint32_t)i[t], jj); sum += v[t];
-		if (row_nnz) { atomicAdd((unsigned long long *)&row_nnz[i[t]], 1ull); atomicAdd(&row_sum[i[t]], v[t]); }
+		const unsigned long long h = mix64((uint32_t)i[t], jj);
+		++cnt; hash += h; sum += v[t];
+		if (row_nnz) { atomicAdd((unsigned long long *)&row_nnz[i[t]], 1ull); atomicAdd(&row_sum[i[t]], v[t]); atomicAdd(&row_hash[i[t]], h); }
 	}
 	digest_flush<256>(slots, cnt, hash, sum, s_u64, s_f64);
 }
@@ -309,6 +310,23 @@ __global__ void k_block_place(const int32_t *i, const int32_t *j, const double *
 	const int32_t r = i[t];
 	const int64_t d = rowoff[r] + (int64_t)cur[r] + (int64_t)(t - rp[r]);
 	oi[d] = r; oj[d] = j[t]; ov[d] = v[t];
+}
+
+// DIGEST | ROWSTATS: the context's three per-row arrays (tuple count, value sum, index hash), zeroed
+static void rowstats_begin(spsamd_ctx *c, uint64_t nrow, SinkParams &sk, spsamd_result *res)
+{
+	c->rowstat_n.ensure(nrow * sizeof(long long));
+	c->rowstat_s.ensure(nrow * sizeof(double));
+	c->rowstat_h.ensure(nrow * sizeof(unsigned long long));
+	fill_zero(c, c->rowstat_n.p, nrow * sizeof(long long));
+	fill_zero(c, c->rowstat_s.p, nrow * sizeof(double));
+	fill_zero(c, c->rowstat_h.p, nrow * sizeof(unsigned long long));
+	sk.row_nnz = (long long *)c->rowstat_n.p;
+	sk.row_sum = (double *)c->rowstat_s.p;
+	sk.row_hash = (unsigned long long *)c->rowstat_h.p;
+	res->row_nnz = (const int64_t *)sk.row_nnz;
+	res->row_sum = sk.row_sum;
+	res->row_hash = (const uint64_t *)sk.row_hash;
 }
 
 static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res, const uint32_t *aptr, const int32_t *acol, const double *aval,
@@ -336,14 +354,7 @@ static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res,
 		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
 		sk.digest = slots;
 		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) {
-			c->rowstat_n.ensure(A.nrow * sizeof(long long));
-			c->rowstat_s.ensure(A.nrow * sizeof(double));
-			fill_zero(c, c->rowstat_n.p, A.nrow * sizeof(long long));
-			fill_zero(c, c->rowstat_s.p, A.nrow * sizeof(double));
-			sk.row_nnz = (long long *)c->rowstat_n.p;
-			sk.row_sum = (double *)c->rowstat_s.p;
-			res->row_nnz = (const int64_t *)sk.row_nnz;
-			res->row_sum = sk.row_sum;
+			rowstats_begin(c, A.nrow, sk, res);
 		}
 		launch_light_direct_s<MODE_DIGEST>(c, maxp, nrow, aptr, acol, aval, bptr, B, k64, ep, sk, pc);
 		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS, sk.err);
@@ -535,14 +546,7 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
 		sk.digest = slots;
 		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) {
-			c->rowstat_n.ensure(A.nrow * sizeof(long long));
-			c->rowstat_s.ensure(A.nrow * sizeof(double));
-			fill_zero(c, c->rowstat_n.p, A.nrow * sizeof(long long));
-			fill_zero(c, c->rowstat_s.p, A.nrow * sizeof(double));
-			sk.row_nnz = (long long *)c->rowstat_n.p;
-			sk.row_sum = (double *)c->rowstat_s.p;
-			res->row_nnz = (const int64_t *)sk.row_nnz;
-			res->row_sum = sk.row_sum;
+			rowstats_begin(c, A.nrow, sk, res);
 		}
 		SPS_HIP(hipEventRecord(c->ev[3], st));
 		launch_light<MODE_DIGEST>(c, bins, m, ep, sk);
@@ -636,18 +640,14 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 		~Blocks() { for (auto &x : b) { (void)hipFree(x.i); (void)hipFree(x.j); (void)hipFree(x.v); } }
 	} blocks;
 	DigestSlot *slots = nullptr;
-	long long *row_nnz = nullptr; double *row_sum = nullptr;
+	SinkParams rsk{};
+	spsamd_result rres{};
 	if (!coo) {
 		slots = c->arena.get<DigestSlot>(DIGEST_SLOTS + 1);
 		fill_zero(c, slots, (DIGEST_SLOTS + 1) * sizeof(DigestSlot));
-		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) {
-			c->rowstat_n.ensure(A.nrow * sizeof(long long));
-			c->rowstat_s.ensure(A.nrow * sizeof(double));
-			fill_zero(c, c->rowstat_n.p, A.nrow * sizeof(long long));
-			fill_zero(c, c->rowstat_s.p, A.nrow * sizeof(double));
-			row_nnz = (long long *)c->rowstat_n.p; row_sum = (double *)c->rowstat_s.p;
-		}
+		if (a.sink_flags & SPSAMD_SINK_ROWSTATS) rowstats_begin(c, A.nrow, rsk, &rres);
 	}
+	long long *const row_nnz = rsk.row_nnz; double *const row_sum = rsk.row_sum; unsigned long long *const row_hash = rsk.row_hash;
 	spsamd_result acc{};
 	for (uint32_t s = 0; s < nblk; ++s) {
 		const uint64_t c0 = (uint64_t)s * colblk, c1 = std::min<uint64_t>(B.ncol, c0 + colblk);
@@ -680,7 +680,7 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 			acc.ms_heavy += rs.ms_heavy; acc.ms_dense += rs.ms_dense; acc.ms_tiles += rs.ms_tiles;
 			if (rs.nnz) {
 				if (!coo) {
-					k_block_digest<<<dim3(std::min<unsigned>(grid_for((size_t)rs.nnz), 4096u)), dim3(256), 0, st>>>(rs.idx0, rs.idx1, rs.val, rs.nnz, (uint32_t)c0, slots, row_nnz, row_sum);
+					k_block_digest<<<dim3(std::min<unsigned>(grid_for((size_t)rs.nnz), 4096u)), dim3(256), 0, st>>>(rs.idx0, rs.idx1, rs.val, rs.nnz, (uint32_t)c0, slots, row_nnz, row_sum, row_hash);
 					SPS_LAUNCH_CHECK();
 				} else {
 					BlockOut bo;
@@ -712,7 +712,7 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 		SPS_LAUNCH_CHECK();
 		const DigestSlot d = read_back(c, slots + DIGEST_SLOTS);
 		res->nnz = d.count; res->hash = d.hash; res->sum = d.sum;
-		if (row_nnz) { res->row_nnz = (const int64_t *)row_nnz; res->row_sum = row_sum; }
+		if (row_nnz) { res->row_nnz = (const int64_t *)row_nnz; res->row_sum = row_sum; res->row_hash = (const uint64_t *)row_hash; }
 		return;
 	}
 	// ---- interleave the blocks row by row

@@ -62,6 +62,7 @@ struct SinkParams {
 	int32_t *out_i; int32_t *out_j; double *out_v;
 	DigestSlot *digest;             // DIGEST_SLOTS accumulators
 	long long *row_nnz; double *row_sum;   // optional row statistics (DIGEST)
+	unsigned long long *row_hash;          // ... and the row's own index hash, sum of mix64(i, j) over its tuples
 	uint32_t *err;                  // device error word: a kernel that meets a state the host promised cannot occur sets a bit
 #ifdef SPSAMD_STAMPS
 	unsigned long long *stamps;     // diagnostic builds only: per-workgroup cycle counters of k_dense's phases

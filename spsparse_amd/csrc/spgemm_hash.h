@@ -196,7 +196,7 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 		block_exclusive_scan<uint32_t, NT>(c, scr32, &total);
 		if (tid == 0) sk.segcount[seg] = total;
 	} else if (MODE == MODE_DIGEST) {
-		unsigned long long cnt = 0; double vs = 0;
+		unsigned long long cnt = 0, rh = 0; double vs = 0;
 		for (uint32_t base = 0; base < nocc; base += NT) {                 // (uniform trips: pat_fix_wave wants whole waves)
 			const uint32_t i = base + tid;
 			const bool valid = i < nocc;
@@ -206,14 +206,15 @@ __device__ __forceinline__ void hash_emit(uint32_t nocc, int32_t rowid, uint32_t
 			double x = valid ? h_val[h] : 0.0;
 			if (PAT) x = pat_fix_wave(valid && !(fabs(x) > pthr), x, col, m, pbeg, pend);
 			if (valid) {
-				if (emit_value(ep, a_scale, col, x, &v)) { ++cnt; d.hash += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
+				if (emit_value(ep, a_scale, col, x, &v)) { ++cnt; rh += mix64((uint32_t)rowid, (uint32_t)col); vs += v; }
 				h_key[h] = -1; h_val[h] = 0.0;
 			}
 		}
-		d.cnt += cnt; d.sum += vs;
+		d.cnt += cnt; d.sum += vs; d.hash += rh;
 		if (sk.row_nnz) {
 			unsigned long long rc = wave_reduce_sum(cnt); double rs = wave_reduce_sum(vs);
-			if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); }
+			rh = wave_reduce_sum(rh);
+			if (lane_id() == 0 && rc) { atomicAdd((unsigned long long *)&sk.row_nnz[rowid], rc); atomicAdd(&sk.row_sum[rowid], rs); atomicAdd(&sk.row_hash[rowid], rh); }
 		}
 	} else {
 		// surviving columns -> sorted -> emitted in order, cleaning the table.  Where the cell's column

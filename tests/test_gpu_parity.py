@@ -1141,6 +1141,43 @@ def test_cfg2_rmat20_full_size_properties(ctx):
     assert d.products == 20924218068 and d.nnz_a == 16086131
     d2 = ctx.multiply(A, A, sink=capi.SINK_DIGEST)
     assert (d2.nnz, d2.hash) == (d.nnz, d.hash)          # index set independent of the atomics' order
+    # ... and pinned to the oracle: the checker's streaming digest of the WHOLE product (2.1e10 scalar products on the
+    # host cores) -- tuple count, index hash, and per output row its tuple count and its own index hash.  This is where
+    # the kernels only this size selects by default meet the oracle (tests/test_multiply_sparse.cpp:119-128's per-cell
+    # check, as far as 9.7e9 cells can be held: per row).
+    w = orc.multiply_digest(orc.Mat(*a), orc.Mat(*a), nthreads=orc.host_threads(), rowstats=True)
+    assert (w.products, w.nnz_a) == (d.products, d.nnz_a)
+    assert (d.nnz, d.hash) == (w.nnz, w.hash)
+    assert np.array_equal(rn, w.row_nnz)
+    assert np.array_equal(ctx.to_host(d.row_hash, n, np.uint64), w.row_hash)
+    assert abs(d.sum - w.sum) <= 1e-10 * abs(w.sum)
+
+
+@pytest.mark.parametrize("flags", [0, 8], ids=["arrival_order", "exact_pattern"])
+def test_rmat18_whole_product_against_the_oracle_digest(ctx, flags):
+    """R-MAT scale-18 A*A (2.9e9 products, nnz(C) = 1.28e9) from raw device-resident tuples: digest and per-row
+    statistics equal the oracle's streaming digest; the COO sink delivers the same count."""
+    from spsparse_amd import capi
+    scale, seed = 18, 1
+    n, ne = 1 << scale, 16 << scale
+    A, keep = _device_operand(ctx, lambda *p: ctx.gen_rmat(scale, seed, 0, ne, *p), ne, (n, n))
+    d = ctx.multiply(A, A, sink=capi.SINK_DIGEST, flags=capi.SINK_ROWSTATS | flags)
+    a = wl.rmat(scale, seed)
+    w = orc.multiply_digest(orc.Mat(*a), orc.Mat(*a), nthreads=orc.host_threads(), rowstats=True)
+    assert (d.nnz, d.hash, d.products, d.nnz_a) == (w.nnz, w.hash, w.products, w.nnz_a)
+    assert np.array_equal(ctx.to_host(d.row_nnz, n, np.int64), w.row_nnz)
+    assert np.array_equal(ctx.to_host(d.row_hash, n, np.uint64), w.row_hash)
+    assert abs(d.sum - w.sum) <= 1e-10 * abs(w.sum)
+    if flags == 0:
+        r = ctx.multiply(A, A, sink=capi.SINK_COO)
+        assert r.nnz == w.nnz
+        # the stored tuples' own digest, from the device arrays (row-major order: the row of the last tuple is the last non-empty one)
+        ci = ctx.to_host(r.idx0, int(r.nnz), np.int32)
+        assert np.array_equal(np.bincount(ci, minlength=n), w.row_nnz)
+        cj = ctx.to_host(r.idx1, int(r.nnz), np.int32)
+        with np.errstate(over="ignore"):
+            assert int(np.sum(orc.mix64(ci, cj), dtype=np.uint64)) == w.hash
+    del keep
 
 
 def test_cfg3_poisson4096_full_size_properties(ctx):
@@ -1257,5 +1294,17 @@ def test_cfg4_rmat23_single_gpu_properties(ctx):
     assert d.nnz_a == key.size == d.nnz_b
     assert d.products == int(rowlen[(key % n).astype(np.int64)].sum())
     assert 1.0e11 < d.nnz < d.products and 3.0e11 < d.products < 4.5e11
+    # pinned to the oracle on a fixed sample of the output rows (every 16th row starting at 5: hub rows, whose dense
+    # cells only this size cuts with 16384-column windows, are among them): per row the tuple count and the index hash
+    mask = np.zeros(n, np.uint8)
+    mask[5::16] = 1
+    mask[:64] = 1                                 # the heaviest rows of an un-permuted R-MAT are the first ones
+    Ah = orc.Mat(a0, a1, av, (n, n))
+    w = orc.multiply_digest(Ah, Ah, nthreads=orc.host_threads(), row_mask=mask, rowstats=True)
+    assert w.nnz_a == d.nnz_a
+    sel = mask == 1
+    assert np.array_equal(rn[sel], w.row_nnz[sel])
+    assert np.array_equal(ctx.to_host(d.row_hash, n, np.uint64)[sel], w.row_hash[sel])
+    assert w.nnz == int(rn[sel].sum())
     del keep
     torch.cuda.empty_cache()

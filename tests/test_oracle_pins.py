@@ -257,6 +257,56 @@ def test_rowwise_equals_innerproduct_with_nan_and_zero_nan():
             assert np.array_equal(x[2], y[2], equal_nan=True)
 
 
+def test_streaming_digest_equals_the_stored_product():
+    """The streaming digest mode of the checker (count, index hash, value sum, per-row count and hash; rows handed
+    out dynamically; optional row mask) against the digest of the restated reference's stored tuples: transposes x
+    scale vectors x C != 1 x duplicate policies x zero_nan, one and several threads."""
+    rng = np.random.default_rng(23)
+    for trial in range(24):
+        m, k, n = rng.integers(1, 60, 3)
+        tA, tB = ".T"[trial % 2], ".T"[(trial // 2) % 2]
+        A = _rand_mat(rng, (k, m) if tA == "T" else (m, k), int(rng.integers(1, 500)), zeros=True)
+        B = _rand_mat(rng, (n, k) if tB == "T" else (k, n), int(rng.integers(1, 500)), zeros=True)
+        si = _rand_vec(rng, m) if trial % 2 else None
+        sj = _rand_vec(rng, k) if trial % 3 else None
+        sk = _rand_vec(rng, n) if trial % 4 == 1 else None
+        dup = [orc.ADD, orc.LEAVE_ALONE, orc.REPLACE][trial % 3]
+        zn = trial % 5 == 0
+        if zn:
+            B.val[rng.integers(0, B.val.size, max(1, B.val.size // 8))] = np.nan
+        wi, wj, wv, _ = orc.multiply(A, B, 3.0, si, tA, sj, tB, sk, dup, zero_nan=zn)
+        keep = ~np.isnan(wv)
+        cnt, _, h = orc.digest(wi, wj, wv)
+        for nt in (1, 4):
+            d = orc.multiply_digest(A, B, 3.0, si, tA, sj, tB, sk, dup, zero_nan=zn, nthreads=nt, rowstats=True)
+            assert (d.nnz, d.hash) == (cnt, h)
+            assert np.array_equal(d.row_nnz, np.bincount(wi, minlength=m))
+            rh = np.zeros(m, np.uint64)
+            np.add.at(rh, wi, orc.mix64(wi, wj))
+            assert np.array_equal(d.row_hash, rh)
+            if keep.all():
+                assert abs(d.sum - wv.sum()) <= 1e-12 * np.abs(wv).sum()
+        mask = (rng.uniform(size=m) < 0.4).astype(np.uint8)
+        d = orc.multiply_digest(A, B, 3.0, si, tA, sj, tB, sk, dup, zero_nan=zn, nthreads=3, row_mask=mask, rowstats=True)
+        sel = mask[wi] == 1
+        assert d.nnz == int(sel.sum()) and d.hash == orc.digest(wi[sel], wj[sel], wv[sel])[2]
+        assert np.array_equal(d.row_nnz, np.bincount(wi[sel], minlength=m))
+
+
+def test_large_inputs_sort_by_radix_to_the_same_permutation():
+    """orc_sorted_permutation takes a stable LSD radix sort from 65536 tuples on (BASELINE-size operands); it must be
+    the permutation of the restated std::stable_sort (algorithm.hpp:411-427), duplicates keeping insertion order."""
+    rng = np.random.default_rng(3)
+    n = 150000
+    i0 = rng.integers(0, 700, n).astype(np.int32)
+    i1 = rng.integers(0, 70000, n).astype(np.int32)
+    for so in (0, 1):
+        assert np.array_equal(orc.sorted_permutation(i0, i1, so), orc.sorted_permutation_merge(i0, i1, so))
+    assert np.array_equal(orc.sorted_permutation(i1, None, 0), orc.sorted_permutation_merge(i1, None, 0))
+    i0[5] = -3                                   # a negative index: the merge sort handles it (no radix path)
+    assert np.array_equal(orc.sorted_permutation(i0, i1, 0), orc.sorted_permutation_merge(i0, i1, 0))
+
+
 def test_ab_equals_btat_transposed():
     """multiply_sparse.hpp:15-18 doc example: AB == (B^T A^T)^T, bitwise."""
     rng = np.random.default_rng(3)
