@@ -319,8 +319,27 @@ def main():
         finish()
         return
 
+    if args.rehearse_gloo:
+        dd = capi.Dist(ctx, rank, world, transport=sd.host_transport(ctx, world))
+    else:
+        # the communicator is the library's own, created from a unique id that rank 0 hands out through torch.distributed
+        uid = [capi.Dist.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        dd = capi.Dist(ctx, rank, world, unique_id=uid[0])
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
     if args.workload == "galerkin":
-        raise SystemExit("--workload galerkin is a single-GPU line here (its 2-GPU split is covered by tests/test_dist_gloo.py)")
+        line = galerkin_sharded(args, torch, dist, capi, sd, ctx, dd, dev, coll_dev, rank, world, barrier)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dd.close()
+        ctx.close()
+        dist.destroy_process_group()
+        finish()
+        return
     if args.workload == "poisson":
         g = args.grid or 4096
         n, ne = g * g, 5 * g * g - 4 * g
@@ -367,14 +386,7 @@ def main():
     del c0, c1, cv, P, rowlen, cost
 
     # the step itself lives behind the C ABI (spsamd_dist_multiply): consolidate the own block, exchange the needed
-    # B row panels with grouped ncclSend / ncclRecv, multiply.  The communicator is the library's own, created
-    # from a unique id that rank 0 hands out through torch.distributed.
-    if args.rehearse_gloo:
-        dd = capi.Dist(ctx, rank, world, transport=sd.host_transport(ctx, world))
-    else:
-        uid = [capi.Dist.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        dd = capi.Dist(ctx, rank, world, unique_id=uid[0])
+    # B row panels with grouped ncclSend / ncclRecv, multiply.
 
     def take_block(b):
         keep = (raw0 >= b[rank]) & (raw0 < b[rank + 1])
@@ -412,10 +424,6 @@ def main():
         res, remote, _ = run_block(block)
         return res, remote
 
-    def barrier():
-        dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     barrier()
@@ -445,6 +453,87 @@ def main():
     ctx.close()
     dist.destroy_process_group()
     finish()
+
+
+def galerkin_sharded(args, torch, dist, capi, sd, ctx, dd, dev, coll_dev, rank, world, barrier):
+    """cfg5 on N ranks (BASELINE: 2): the Galerkin triple product R*A*R^T of the 7-point Laplacian on a g^3 mesh, 2x2x2
+    aggregation, cut along z planes: rank q owns the coarse planes [zc_q, zc_q+1) -- its rows of R, T and C -- and the
+    fine planes under them -- its rows of A and its tuples of R^T.  T = R*A needs no remote row of A (the fine cells of
+    an aggregate lie in the rank's own planes); C = T*R^T needs the R^T rows of one fine plane on either side (SURVEY
+    8e).  Both products are spsamd_dist_multiply; T is chained from the first into the second in place."""
+    g = args.grid or 256
+    nc = g // 2
+    na = 7 * g ** 3 - 6 * g ** 2
+    nr = g ** 3
+
+    def bufs(m):
+        return (torch.empty(m, dtype=torch.int32, device=dev), torch.empty(m, dtype=torch.int32, device=dev),
+                torch.empty(m, dtype=torch.float64, device=dev))
+    ta, tr = bufs(na), bufs(nr)
+    ctx.gen_laplace3d(g, *[x.data_ptr() for x in ta])
+    ctx.gen_aggregation3d(g, *[x.data_ptr() for x in tr])
+    torch.cuda.synchronize()
+    zc = [nc * q // world for q in range(world + 1)]                  # coarse planes per rank
+    bounds_c = [z * nc * nc for z in zc]                             # rows of R / T / C
+    bounds_f = [2 * z * g * g for z in zc]                           # rows of A = inner index of R*A; columns of R = inner index of T*R^T
+
+    def take(t, dim, lo, hi):
+        keep = (t[dim] >= lo) & (t[dim] < hi)
+        return tuple(x[keep].contiguous() for x in t)
+    Rrows = take(tr, 0, bounds_c[rank], bounds_c[rank + 1])          # A_block of R*A
+    Arows = take(ta, 0, bounds_f[rank], bounds_f[rank + 1])          # B_block of R*A: op(B) = A, rows = fine cells
+    Rcols = take(tr, 1, bounds_f[rank], bounds_f[rank + 1])          # B_block of T*R^T: op(B) = R^T, rows = fine cells = R's columns
+    del ta, tr
+    torch.cuda.empty_cache()
+    shapeA, shapeR = (g ** 3, g ** 3), (nc ** 3, g ** 3)
+
+    def coo(t, shape, sort0=0):
+        return capi.device_coo(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[0].numel(), shape, sort0)
+    Rb, Ab, Rc = coo(Rrows, shapeR), coo(Arows, shapeA), coo(Rcols, shapeR, sort0=-1)
+    ctx.reserve(int((na + nr) // world * 300) + (512 << 20))
+
+    def step(sink2=capi.SINK_COO):
+        rt, st1 = dd.multiply(Rb, Ab, bounds_f, sink=capi.SINK_COO)
+        rc, st2 = dd.multiply(capi.result_operand(rt), Rc, bounds_f, tB="T", sink=sink2)
+        return rt, rc, int(st1.remote_tuples) + int(st2.remote_tuples)
+
+    step()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    results = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+    rt, rc, remote = results[-1]
+    # untimed: the same second product into the digest sink, for the whole-job digest of C
+    _, rd, _ = step(capi.SINK_DIGEST)
+    stats = torch.tensor([rt.nnz_a, rt.products, rt.nnz, rc.products, rc.nnz, remote], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(stats)
+    nnz_r, p1, nnz_t, p2, nnz_c, remote_total = [int(x) for x in stats.tolist()]
+    cnt, vsum, vhash = sd.reduce_digest(int(rd.nnz), float(rd.sum), int(rd.hash), coll_dev)
+    assert cnt == nnz_c
+    ms_step = elapsed / args.steps * 1e3
+    read_alg = 16 * nnz_r + 12 * p1 + 16 * nnz_t + 12 * p2
+    return {
+        "metric": "nnz(C)/s for C=R*A*R^T (two chained SpGEMMs)", "value": nnz_c * args.steps / elapsed, "unit": "nnz(C)/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "Galerkin triple product R*A*R^T, 7-point Laplacian on a %d^3 mesh, 2x2x2 aggregation, fp64, cut along z planes: "
+                        "T = R*A (no remote rows), C = T*R^T reading T in place (one-plane halo of R^T), COO sinks" % g,
+            "parallelism": "%d row blocks of R / T / C at coarse z planes, A and R^T at the fine planes under them + all-to-allv of "
+                           "needed B row panels (spsamd_dist_multiply with 'T' for R^T)" % world,
+            "sink": "coo", "sink_flags": 0,
+            "nnz_r": nnz_r, "nnz_t": nnz_t, "nnz_c": nnz_c, "products": [p1, p2], "remote_panel_tuples": remote_total,
+            "digest": {"sum": vsum, "hash": "%016x" % vhash},
+            "read_alg_GBps": read_alg / (ms_step * 1e-3) / 1e9,
+            "read_alg_frac_of_hbm_peak": read_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        },
+    }
 
 
 def roofline_of(args, world, results, scale_is_cfg2):
@@ -538,8 +627,15 @@ def single_gpu(args, torch, capi, ctx, dev, stream):
     flat = [r for step in results for r in step] if w.kind == "galerkin" else [step[0] for step in results]
     nnz_a, products, nnz_c = sum(summary["nnz_a"]), sum(summary["products"]), summary["nnz_c"][-1]
     elapsed = summary["ms_per_step"] * 1e-3 * args.steps
+    dsum, dhash = float(last[-1].sum), int(last[-1].hash)
+    if w.kind == "galerkin":
+        # untimed: the second product once more into the digest sink, so that the line carries C's digest like the others
+        rt = ctx.multiply(w.R, w.A, sink=capi.SINK_COO)
+        rd = ctx.multiply(capi.result_operand(rt), w.R, tB="T", sink=capi.SINK_DIGEST)
+        assert int(rd.nnz) == nnz_c
+        dsum, dhash = float(rd.sum), int(rd.hash)
     line = headline(args, 1, w.name, w.n, w.ne, nnz_a, products, nnz_c,
-                    float(last[-1].sum), int(last[-1].hash), summary["ms_per_step"], elapsed,
+                    dsum, dhash, summary["ms_per_step"], elapsed,
                     [step[-1] for step in results] if w.kind == "galerkin" else flat, 0, None, "1 GPU")
     if w.kind == "galerkin":
         line["metric"] = "nnz(C)/s for C=R*A*R^T (two chained SpGEMMs)"

@@ -51,6 +51,7 @@ extern "C" {
 #define SPSAMD_ENOMEM      (-4)   /* device or host allocation failed */
 #define SPSAMD_ECAPACITY   (-5)   /* caller-supplied output buffer too small */
 #define SPSAMD_ENODEVICE   (-6)   /* no usable gfx950 device */
+#define SPSAMD_EPEER       (-7)   /* multi-GPU step: another rank of the communicator reported an error (nothing was multiplied) */
 
 /* spsparse::DuplicatePolicy (spsparse.hpp:25-26), same enumerator order */
 #define SPSAMD_LEAVE_ALONE 0
@@ -281,17 +282,43 @@ int spsamd_sorted_permutation(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uin
  */
 int spsamd_dim_beginnings(spsamd_ctx *ctx, const spsamd_coo *A, int so0, uint64_t *beginnings_host, size_t *count);
 
-/* ---- multi-GPU: A sharded by contiguous row blocks, one rank per GPU ----
- * The reference has no counterpart.  Output row i depends only on row i of op(A) and the B rows
- * {k : A(i,k) != 0} (the reference's own loop structure, multiply_sparse.hpp:192): every rank multiplies its
- * row block of A with the panel of B rows it needs, fetched with ONE exchange step (grouped ncclSend / ncclRecv
- * over RCCL: the all-to-allv of needed B row panels); C stays row partitioned, there is no reduction.
+/* ---- prepared operands ----
+ * What a multiply derives from an operand before it starts -- the consolidated tuples, the row structure, the
+ * (col, val)-interleaved copy and, for products with heavy rows, the column-window indices of the right operand -- kept
+ * in device memory so that it is derived ONCE for an operand that takes part in many products.  The reference does the
+ * same on the host: an array that carries the wanted sort_order is not consolidated again (Consolidate<>,
+ * algorithm.hpp:360) and its row structure is cached inside the object (VectorCooArray.hpp:325-335).
+ *   role       SPSAMD_AS_A, SPSAMD_AS_B or both: the side(s) of multiply the operand will stand on
+ *   transpose  the transpose flag it will be passed with
+ *   duplicate_policy, zero_nan: as for multiply; they are applied HERE, once (a multiply takes a prepared operand as it
+ *              is, the way Consolidate<> takes a sorted one)
+ * spsamd_operand_as_coo fills a spsamd_coo (mem = SPSAMD_MEM_PREPARED) that is accepted wherever an operand is; results
+ * are identical to those of the plain operand.  A handle belongs to the context that prepared it and is immutable; the
+ * structures only heavy rows need are built by the first multiply that needs them and stay (not re-entrant on one
+ * handle from two threads, like the reference's lazy cache).  Used with the other transpose flag than it was prepared
+ * for, the handle is read as an ordinary device operand sorted the other way (and consolidated by that call). */
+#define SPSAMD_MEM_PREPARED 2
+#define SPSAMD_AS_A 1
+#define SPSAMD_AS_B 2
+typedef struct spsamd_operand spsamd_operand;
+int spsamd_operand_prepare(spsamd_ctx *ctx, const spsamd_coo *X, char transpose, int role, int duplicate_policy, int zero_nan,
+	spsamd_operand **out);
+int spsamd_operand_as_coo(const spsamd_operand *op, spsamd_coo *out);
+uint64_t spsamd_operand_bytes(const spsamd_operand *op);     /* device memory the handle holds right now */
+void spsamd_operand_destroy(spsamd_operand *op);
+
+/* ---- multi-GPU: op(A) sharded by contiguous row blocks, one rank per GPU ----
+ * The reference has no counterpart.  Output row i depends only on row i of op(A) and the op(B) rows
+ * {k : op(A)(i,k) != 0} (the reference's own loop structure, multiply_sparse.hpp:192): every rank multiplies its row
+ * block of op(A) with the panel of op(B) rows it needs, fetched with ONE exchange step (grouped ncclSend / ncclRecv over
+ * RCCL: the all-to-allv of needed B row panels); C stays row partitioned, there is no reduction.
  */
 typedef struct spsamd_dist spsamd_dist;
 
 /* Optional transport replacing the built-in RCCL one (tests: gloo / MPI through host memory).  All-to-allv of
  * device buffers: send[p] (sendbytes[p] bytes) goes to rank p, recvbytes[p] bytes from rank p arrive in recv[p].
- * The buffers are complete when it is called and must be complete when it returns. */
+ * The buffers are complete when it is called and must be complete when it returns.  A step calls it several times
+ * (once per kind of payload); every rank makes the same sequence of calls. */
 typedef int (*spsamd_alltoallv_fn)(void *user, const void *const *send, const size_t *sendbytes,
 	void *const *recv, const size_t *recvbytes, int world, void *hip_stream);
 
@@ -300,7 +327,8 @@ typedef struct {
 	uint64_t panel_tuples;        /* tuples of the B panel this rank multiplied with */
 	uint64_t remote_tuples;       /* ... of which received from other ranks */
 	uint64_t sent_tuples;         /* tuples this rank sent to other ranks */
-	float ms_exchange;            /* consolidate + masks + pack + exchange, before the block product (HIP events) */
+	float ms_exchange;            /* consolidation of the blocks + both exchange rounds up to the issue of the panel transfer
+	                               * (HIP events; the transfer itself overlaps the product's symbolic phase) */
 	float pad_;
 } spsamd_dist_stats;
 
@@ -308,20 +336,39 @@ typedef struct {
  * torch.distributed ...), then spsamd_dist_create(..., unique_id, ...) on every rank. */
 int spsamd_dist_unique_id(char id[128]);
 /* One of: unique_id (the library creates its communicator with ncclCommInitRank), nccl_comm (an ncclComm_t of
- * the caller, borrowed), or transport (+ transport_user).  ctx: this rank's context (its device and stream). */
+ * the caller, borrowed), or transport (+ transport_user).  ctx: this rank's context (its device and stream).
+ * At most 64 ranks. */
 int spsamd_dist_create(spsamd_dist **out, spsamd_ctx *ctx, int rank, int world, const char *unique_id,
 	void *nccl_comm, spsamd_alltoallv_fn transport, void *transport_user);
 void spsamd_dist_destroy(spsamd_dist *d);
 /*
- * One step.  A_block: this rank's row block of A -- raw COO tuples with GLOBAL indices, shape = the whole
- * matrix's.  B_block: the tuples of B whose row lies in [b_bounds[rank], b_bounds[rank+1]), or NULL for
- * A * A when the A blocks are cut at b_bounds too (the own A block then is the own B block).
- * b_bounds: world + 1 ascending row boundaries of B's distribution over the inner dimension (0 .. inner).
- * The result is this rank's rows of C in the sink of its context (digest: add the counts / hashes / sums of all
- * ranks; COO: tuples with global indices).  Collective: every rank of the communicator must call it.
+ * One step: this rank's rows of  C * diag(scalei) * op(A) * diag(scalej) * op(B) * diag(scalek)  -- the arguments of
+ * spsparse::multiply (multiply_sparse.hpp:138-150) with the two matrices given block-wise:
+ *   A_block  the tuples of A that belong to this rank's rows of op(A) -- raw COO with GLOBAL indices, shape = the whole
+ *            matrix's, in their original relative order (which rows a rank owns is the caller's choice: any partition).
+ *   B_block  the tuples of B whose op(B) ROW -- the inner index: idx0 without 'T', idx1 with it -- lies in
+ *            [b_bounds[rank], b_bounds[rank+1]); or NULL where B is A with the same transpose flag and the A blocks
+ *            are cut at b_bounds too (A * A: the own A block then is the own B block).
+ *   b_bounds world + 1 ascending boundaries of op(B)'s distribution over the inner dimension (0 .. inner), the same on
+ *            every rank.
+ *   scale vectors: whole, the same on every rank.  zero_nan: the NaNs dropped are those of the leading run of the WHOLE
+ *            matrix' sorted sequence, as in the reference (algorithm.hpp:272-275): the ranks agree on it first.
+ * The result is this rank's rows of C in the sink of its context (digest: add the counts / hashes / sums of all ranks;
+ * COO: tuples with global indices, chainable as the A_block of the next step: T = R*A, then C = T*R^T).
+ * Collective: every rank of the communicator must call it, with the same shapes, bounds, flags and policies.  A rank
+ * whose own operands are bad (index out of bounds, a B_block tuple outside its bounds ...) still takes part in the first
+ * exchange round, which carries every rank's status: then EVERY rank returns an error -- its own, or SPSAMD_EPEER -- and
+ * the communicator stays usable.  A failure after that round (out of memory, a HIP / RCCL error) cannot be agreed on any
+ * more: the communicator refuses further steps (SPSAMD_EPEER); destroy it and create a new one.
  */
-int spsamd_dist_multiply(spsamd_dist *d, double C, const spsamd_coo *A_block, const spsamd_coo *B_block,
-	const uint64_t *b_bounds, int duplicate_policy, int zero_nan, int sink_kind, int sink_flags,
+int spsamd_dist_multiply(spsamd_dist *d, double C,
+	const spsamd_vec *scalei,
+	const spsamd_coo *A_block, char transpose_A,
+	const spsamd_vec *scalej,
+	const spsamd_coo *B_block, char transpose_B,
+	const spsamd_vec *scalek,
+	const uint64_t *b_bounds,
+	int duplicate_policy, int zero_nan, int sink_kind, int sink_flags,
 	spsamd_result *result, spsamd_dist_stats *stats);
 
 /* ---- synthetic operands generated on the device (bench / tests) ----

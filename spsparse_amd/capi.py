@@ -14,14 +14,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPSAMD_LIB") or os.path.join(_HERE, "lib", "libspsparse_amd.so")    # SPSAMD_LIB: a developer variant build
 
 LEAVE_ALONE, ADD, REPLACE = 0, 1, 2
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_PREPARED = 0, 1, 2
+AS_A, AS_B = 1, 2
 SINK_COO, SINK_DIGEST = 1, 2
 SINK_ROWSTATS = 1
 SINK_ORDERED = 2
 SINK_PERMUTE = 4
 SINK_EXACT_PATTERN = 8
 
-ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE"}
+ERRORS = {-1: "EDIM", -2: "EINVAL", -3: "EHIP", -4: "ENOMEM", -5: "ECAPACITY", -6: "ENODEVICE", -7: "EPEER"}
 
 
 class SpsamdError(RuntimeError):
@@ -74,7 +75,8 @@ SYMBOLS = ["spsamd_ctx_create", "spsamd_ctx_destroy", "spsamd_last_error", "spsa
            "spsamd_multiply", "spsamd_multiply_mv", "spsamd_result_fetch", "spsamd_result_scatter_dense", "spsamd_memcpy", "spsamd_consolidate", "spsamd_sorted_permutation",
            "spsamd_dim_beginnings", "spsamd_gen_rmat",
            "spsamd_gen_random_rows", "spsamd_gen_poisson2d", "spsamd_gen_laplace3d", "spsamd_gen_aggregation3d",
-           "spsamd_dist_unique_id", "spsamd_dist_create", "spsamd_dist_destroy", "spsamd_dist_multiply"]
+           "spsamd_dist_unique_id", "spsamd_dist_create", "spsamd_dist_destroy", "spsamd_dist_multiply",
+           "spsamd_operand_prepare", "spsamd_operand_as_coo", "spsamd_operand_bytes", "spsamd_operand_destroy"]
 
 _lib = None
 
@@ -126,8 +128,14 @@ def load():
     L.spsamd_dist_create.argtypes = [P(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, ALLTOALLV_FN, C.c_void_p]
     L.spsamd_dist_destroy.argtypes = [C.c_void_p]
     L.spsamd_dist_destroy.restype = None
-    L.spsamd_dist_multiply.argtypes = [C.c_void_p, C.c_double, P(Coo), P(Coo), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       P(Result), P(DistStats)]
+    L.spsamd_dist_multiply.argtypes = [C.c_void_p, C.c_double, P(Vec), P(Coo), C.c_char, P(Vec), P(Coo), C.c_char, P(Vec), C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, P(Result), P(DistStats)]
+    L.spsamd_operand_prepare.argtypes = [C.c_void_p, P(Coo), C.c_char, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
+    L.spsamd_operand_as_coo.argtypes = [C.c_void_p, P(Coo)]
+    L.spsamd_operand_bytes.argtypes = [C.c_void_p]
+    L.spsamd_operand_bytes.restype = C.c_uint64
+    L.spsamd_operand_destroy.argtypes = [C.c_void_p]
+    L.spsamd_operand_destroy.restype = None
     _lib = L
     return L
 
@@ -277,6 +285,28 @@ class Context:
         self._check(self.L.spsamd_gen_aggregation3d(self.h, N, p0, p1, pv))
 
 
+class Operand:
+    """spsamd_operand: an operand prepared once (consolidated tuples, row structure, and whatever later products build
+    from it), accepted by every entry point through `.coo`."""
+
+    def __init__(self, ctx, X, transpose='.', role=AS_A | AS_B, duplicate_policy=ADD, zero_nan=False):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.L.spsamd_operand_prepare(ctx.h, C.byref(X), transpose.encode(), role, duplicate_policy, int(zero_nan), C.byref(h)))
+        self.h = h
+        self.coo = Coo()
+        ctx._check(ctx.L.spsamd_operand_as_coo(self.h, C.byref(self.coo)))
+
+    @property
+    def bytes(self):
+        return int(self.ctx.L.spsamd_operand_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.spsamd_operand_destroy(self.h)
+            self.h = None
+
+
 class Dist:
     """spsamd_dist: this rank's end of the row-block sharded multiply (one rank per GPU).
 
@@ -312,11 +342,15 @@ class Dist:
         ctx._check(rc)
         self.h = h
 
-    def multiply(self, A_block, B_block, b_bounds, C_=1.0, duplicate_policy=ADD, zero_nan=False, sink=SINK_DIGEST, flags=0):
+    def multiply(self, A_block, B_block, b_bounds, C_=1.0, scalei=None, tA='.', scalej=None, tB='.', scalek=None,
+                 duplicate_policy=ADD, zero_nan=False, sink=SINK_DIGEST, flags=0):
+        """spsamd_dist_multiply: spsparse::multiply's arguments, the two matrices block-wise (collective)."""
         res, stats = Result(), DistStats()
         bb = (C.c_uint64 * len(b_bounds))(*[int(x) for x in b_bounds])
-        rc = self.ctx.L.spsamd_dist_multiply(self.h, float(C_), C.byref(A_block), None if B_block is None else C.byref(B_block),
-                                             bb, duplicate_policy, int(zero_nan), sink, flags, C.byref(res), C.byref(stats))
+        ptr = [None if s is None else C.byref(s) for s in (scalei, scalej, scalek)]
+        rc = self.ctx.L.spsamd_dist_multiply(self.h, float(C_), ptr[0], C.byref(A_block), tA.encode(), ptr[1],
+                                             None if B_block is None else C.byref(B_block), tB.encode(), ptr[2], bb,
+                                             duplicate_policy, int(zero_nan), sink, flags, C.byref(res), C.byref(stats))
         self.ctx._check(rc)
         return res, stats
 

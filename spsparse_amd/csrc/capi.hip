@@ -133,7 +133,7 @@ int spsamd::multiply_body(spsamd_ctx *c, double C,
 	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
 	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
 	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,
-	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready)
+	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready, const OperandParts *parts)
 {
 	if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
 	if (sink_kind != SPSAMD_SINK_COO && sink_kind != SPSAMD_SINK_DIGEST) throw Error{SPSAMD_EINVAL, "bad sink_kind"};
@@ -163,11 +163,15 @@ int spsamd::multiply_body(spsamd_ctx *c, double C,
 	{ const spsamd_coo *ops[2] = {A, B}; pick_output_set(c, ops, 2); }
 	MultiplyArgs a;
 	a.C = C; a.sink_kind = sink_kind; a.sink_flags = sink_flags;
-	consolidate_operand(c, A, a0, a0, duplicate_policy, zero_nan, &a.A);      // :187
+	if (parts) { a.pa = parts->pa; a.pb = parts->pb; a.b_ready = parts->b_ready; }
+	Prepared *hp = nullptr;
+	consolidate_operand(c, A, a0, a0, duplicate_policy, zero_nan, &a.A, &hp);      // :187
+	if (hp) a.pa = hp;
 	// A*A: one consolidation serves both -- except under zero_nan, where the NaNs dropped from B are those
 	// of the leading run of the reference's column-major sequence (:168), not of A's row-major one
-	if (a0 == bk && same_operand(A, B) && !zero_nan) a.B = a.A;
-	else consolidate_operand(c, B, bk, bj, duplicate_policy, zero_nan, &a.B);  // :188
+	// (a prepared operand is taken as it was prepared, like any operand that carries the wanted sort order)
+	if (a0 == bk && same_operand(A, B) && (!zero_nan || hp)) { a.B = a.A; if (a.pa) a.pb = a.pa; }
+	else { consolidate_operand(c, B, bk, bj, duplicate_policy, zero_nan, &a.B, &hp); if (hp) a.pb = hp; }  // :188
 	upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
 	upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
 	upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
@@ -231,6 +235,88 @@ extern "C" int spsamd_multiply_mv(spsamd_ctx *c, double C,
 		res->idx1 = nullptr;                          // ... with one index array: nothing to copy for a second one
 		return rc;
 	)
+}
+
+// ---- prepared operands -------------------------------------------------------------------------------------
+// The reference keeps what it derives from an operand: an array that carries the wanted sort_order is not consolidated
+// again (Consolidate<>, algorithm.hpp:360) and its row structure is computed once and cached in the object
+// (VectorCooArray::dim_beginnings, VectorCooArray.hpp:325-335).  spsamd_operand is that object on the device.
+
+struct spsamd_operand {
+	spsamd::Prepared p;
+	uint64_t shape0 = 0, shape1 = 0;
+};
+
+extern "C" int spsamd_operand_prepare(spsamd_ctx *c, const spsamd_coo *X, char transpose, int role, int duplicate_policy, int zero_nan,
+	spsamd_operand **out)
+{
+	if (!c) return SPSAMD_EINVAL;
+	API_GUARD(c,
+		if (!X || !out) throw Error{SPSAMD_EINVAL, "null operand or result"};
+		*out = nullptr;
+		if (role != SPSAMD_AS_A && role != SPSAMD_AS_B && role != (SPSAMD_AS_A | SPSAMD_AS_B)) throw Error{SPSAMD_EINVAL, "bad role"};
+		if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+		if (X->mem == SPSAMD_MEM_PREPARED) throw Error{SPSAMD_EINVAL, "the operand is a prepared one already"};
+		if (zero_nan && role == (SPSAMD_AS_A | SPSAMD_AS_B))
+			throw Error{SPSAMD_EINVAL, "under zero_nan the two sides of a product drop different NaNs (multiply_sparse.hpp:167-168): prepare one operand per side"};
+		SPS_HIP(hipSetDevice(c->device));
+		c->arena.reset();
+		// the leading dimension multiply consolidates this side by, and the one the REFERENCE's own sequence leads with
+		// (they differ for B: multiply_sparse.hpp:168)
+		const int lead = transpose == 'T' ? 1 : 0;
+		const int ref_lead = (role & SPSAMD_AS_A) ? lead : 1 - lead;
+		ConMat m;
+		consolidate_operand(c, X, lead, ref_lead, duplicate_policy, zero_nan, &m);
+		spsamd_operand *h = new spsamd_operand();
+		struct Guard { spsamd_operand *h; ~Guard() { if (h) { h->p.release(); delete h; } } } guard{h};
+		h->shape0 = X->shape0; h->shape1 = X->shape1;
+		Prepared &p = h->p;
+		p.ctx = c; p.owns = true; p.lead = lead;
+		p.m = m;
+		const size_t n = m.nnz;
+		p.m.row = p.get<int32_t>(n ? n : 1); p.m.col = p.get<int32_t>(n ? n : 1); p.m.val = p.get<double>(n ? n : 1);
+		if (n) {
+			SPS_HIP(hipMemcpyAsync(p.m.row, m.row, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+			SPS_HIP(hipMemcpyAsync(p.m.col, m.col, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+			SPS_HIP(hipMemcpyAsync(p.m.val, m.val, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+		}
+		SPS_HIP(hipStreamSynchronize(c->stream));
+		guard.h = nullptr;
+		*out = h;
+		return SPSAMD_OK;
+	)
+}
+
+extern "C" int spsamd_operand_as_coo(const spsamd_operand *h, spsamd_coo *out)
+{
+	if (!h || !out) return SPSAMD_EINVAL;
+	out->idx0 = (const int32_t *)h; out->idx1 = nullptr; out->val = nullptr;
+	out->nnz = h->p.m.nnz; out->shape0 = h->shape0; out->shape1 = h->shape1;
+	out->sort0 = h->p.lead; out->mem = SPSAMD_MEM_PREPARED;
+	return SPSAMD_OK;
+}
+
+extern "C" uint64_t spsamd_operand_bytes(const spsamd_operand *h) { return h ? h->p.owned_bytes : 0; }
+
+extern "C" void spsamd_operand_destroy(spsamd_operand *h)
+{
+	if (!h) return;
+	if (h->p.ctx) { (void)hipSetDevice(h->p.ctx->device); (void)hipStreamSynchronize(h->p.ctx->stream); if (h->p.ctx->side) (void)hipStreamSynchronize(h->p.ctx->side); }
+	h->p.release();
+	delete h;
+}
+
+// The stand-alone algorithms read an operand's arrays themselves: a prepared operand is handed to them as the device
+// COO it holds (sorted by its lead).
+static const spsamd_coo *plain_operand(spsamd_ctx *c, const spsamd_coo *X, spsamd_coo *tmp)
+{
+	if (!X || X->mem != SPSAMD_MEM_PREPARED) return X;
+	const spsamd_operand *h = (const spsamd_operand *)X->idx0;
+	if (!h || h->p.ctx != c) throw Error{SPSAMD_EINVAL, "a prepared operand belongs to the context that prepared it"};
+	const Prepared &p = h->p;
+	tmp->idx0 = p.lead == 0 ? p.m.row : p.m.col; tmp->idx1 = p.lead == 0 ? p.m.col : p.m.row; tmp->val = p.m.val;
+	tmp->nnz = p.m.nnz; tmp->shape0 = h->shape0; tmp->shape1 = h->shape1; tmp->sort0 = p.lead; tmp->mem = SPSAMD_MEM_DEVICE;
+	return tmp;
 }
 
 extern "C" int spsamd_result_fetch(spsamd_ctx *c, const spsamd_result *res, spsamd_chunk_fn cb, void *user)
@@ -316,6 +402,8 @@ extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, i
 	API_GUARD(c,
 		if (!A || !res || (so0 != 0 && so0 != 1)) throw Error{SPSAMD_EINVAL, "bad argument"};
 		if (duplicate_policy < 0 || duplicate_policy > 2) throw Error{SPSAMD_EINVAL, "bad duplicate_policy"};
+		spsamd_coo plain;
+		A = plain_operand(c, A, &plain);
 		std::memset(res, 0, sizeof(*res));
 		res->shape0 = A->shape0; res->shape1 = A->shape1;
 		if (A->nnz == 0) return SPSAMD_OK;
@@ -348,6 +436,8 @@ extern "C" int spsamd_sorted_permutation(spsamd_ctx *c, const spsamd_coo *A, int
 	API_GUARD(c,
 		if (!A || (so0 != 0 && so0 != 1) || (A->nnz && !perm_host)) throw Error{SPSAMD_EINVAL, "bad argument"};
 		if (A->nnz == 0) return SPSAMD_OK;
+		spsamd_coo plain;
+		A = plain_operand(c, A, &plain);
 		SPS_HIP(hipSetDevice(c->device));
 		c->arena.reset();
 		uint32_t *perm = sorted_permutation(c, A, so0);
@@ -364,6 +454,8 @@ extern "C" int spsamd_dim_beginnings(spsamd_ctx *c, const spsamd_coo *A, int so0
 	if (!c) return SPSAMD_EINVAL;
 	API_GUARD(c,
 		if (!A || !count || (so0 != 0 && so0 != 1)) throw Error{SPSAMD_EINVAL, "bad argument"};
+		spsamd_coo plain;
+		A = plain_operand(c, A, &plain);
 		if (A->sort0 != so0) throw Error{SPSAMD_EINVAL, "dim_beginnings() required the VectorCooArray is sorted first."};
 		*count = 0;
 		if (A->nnz == 0) return SPSAMD_OK;                         // algorithm.hpp:89

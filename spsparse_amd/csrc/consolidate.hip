@@ -19,7 +19,8 @@ static int bits_for(uint64_t dim)
 	return b;
 }
 
-// flags: bit0 = an index is out of [0, shape); bit1 = not (strictly sorted, no zero values)
+// flags: bit0 = an index is out of [0, shape); bit1 = not (strictly sorted, no zero values); bit2 = not strictly in
+// (minor, major) order; bit3 = holds a value consolidate() may drop; bit4 = the major index descends somewhere
 __global__ void k_inspect(const int32_t *major, const int32_t *minor, const double *val, size_t n,
 	uint64_t nrow, uint64_t ncol, int zero_nan, uint32_t *flags)
 {
@@ -34,12 +35,13 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 		if (i > 0) {
 			int32_t pr = major[i - 1], pc = minor[i - 1];
 			if (!(pr < r || (pr == r && pc < c))) f |= 2u;
+			if (pr > r) f |= 16u;                                       // the MAJOR index itself descends: not even row-grouped
 			if (!(pc < c || (pc == c && pr < r))) f |= 4u;          // not STRICTLY in (minor, major) order either
 		}
 	}
 	uint32_t wf = 0;
 #pragma unroll
-	for (uint32_t b = 1u; b <= 8u; b <<= 1) if (__ballot(f & b)) wf |= b;
+	for (uint32_t b = 1u; b <= 16u; b <<= 1) if (__ballot(f & b)) wf |= b;
 	if (wf && lane_id() == 0 && (*(volatile uint32_t *)flags & wf) != wf) atomicOr(flags, wf);
 }
 
@@ -158,8 +160,27 @@ static const T *to_device(spsamd_ctx *c, const T *p, size_t n, int mem)
 	return d;
 }
 
-void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_lead, int duplicate_policy, int zero_nan, ConMat *out)
+__global__ void k_min_key(unsigned long long *first_key, const unsigned long long *global_key)
 {
+	if (*global_key < *first_key) *first_key = *global_key;
+}
+
+void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_lead, int duplicate_policy, int zero_nan, ConMat *out,
+	Prepared **prep, const unsigned long long *global_first_key)
+{
+	if (prep) *prep = nullptr;
+	if (X->mem == SPSAMD_MEM_PREPARED) {
+		// a prepared operand (spsamd_operand_prepare): consolidated once, by the lead it was prepared for.  Used the other way
+		// round ('T' now, '.' then) its tuples are an ordinary device operand sorted by the other dimension.
+		Prepared *p = (Prepared *)const_cast<int32_t *>(X->idx0);
+		if (!p || p->ctx != c) throw Error{SPSAMD_EINVAL, "a prepared operand belongs to the context that prepared it"};
+		if (p->lead == lead) { *out = p->m; if (prep) *prep = p; return; }
+		spsamd_coo Y;
+		Y.idx0 = p->lead == 0 ? p->m.row : p->m.col; Y.idx1 = p->lead == 0 ? p->m.col : p->m.row; Y.val = p->m.val;
+		Y.nnz = p->m.nnz; Y.shape0 = X->shape0; Y.shape1 = X->shape1; Y.sort0 = p->lead; Y.mem = SPSAMD_MEM_DEVICE;
+		consolidate_operand(c, &Y, lead, ref_lead, duplicate_policy, zero_nan, out, nullptr, global_first_key);
+		return;
+	}
 	size_t n = X->nnz;
 	if (n >= (size_t(1) << 31))
 		throw Error{SPSAMD_EINVAL, "operand has 2^31 or more tuples (the reference's int positions cap it too, algorithm.hpp:419)"};
@@ -194,6 +215,11 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	uint32_t f = read_back(c, flags);
 	if (f & 1u) throw Error{SPSAMD_EINVAL, "Sparse index out of bounds (VectorCooArray::add would reject it, VectorCooArray.hpp:246-262)"};
 
+	// A claimed sort order is trusted like Consolidate<> trusts it (algorithm.hpp:360) as far as the ORDER INSIDE A ROW and
+	// duplicates go; rows that are not even ascending would leave the dense row pointer (built from the tuples' side) with
+	// entries nobody wrote -- out-of-bounds reads in the numeric kernels, where the reference would "only" mis-compute.
+	if (X->sort0 == lead && (f & 16u))
+		throw Error{SPSAMD_EINVAL, "operand claims sort_order but its leading index is not ascending (set_sorted() on unsorted tuples?)"};
 	// Consolidate<>: a matching sort_order is trusted (algorithm.hpp:360); so is
 	// an operand the inspection found strictly sorted with no zero values.
 	// (Under zero_nan an operand whose reference order is the other dimension and that holds a 0 / NaN
@@ -242,6 +268,8 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	k_gather_flag<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(dv, ps, ks, n, zero_nan, mb, Mb, swap, sval, keep, first_key);
 	SPS_LAUNCH_CHECK();
 	if (zero_nan) {
+		// (distributed step: the first kept tuple of the WHOLE matrix may sit in another rank's block)
+		if (global_first_key) { k_min_key<<<dim3(1), dim3(1), 0, c->stream>>>(first_key, global_first_key); SPS_LAUNCH_CHECK(); }
 		k_first_pos<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(sval, ps, ks, n, mb, Mb, swap, first_key, first_pos);
 		SPS_LAUNCH_CHECK();
 		k_apply_first<<<dim3(grid_for(n)), dim3(256), 0, c->stream>>>(sval, ps, ks, keep, n, mb, Mb, swap, first_key, first_pos);
@@ -264,6 +292,38 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 		out->row, out->col, out->val);
 	SPS_LAUNCH_CHECK();
 	out->nnz = read_back(c, hpos + n);
+}
+
+// The smallest reference-order key among the tuples of X (device arrays) that consolidate() keeps whatever zero_nan says --
+// neither 0 nor NaN -- as k_gather_flag finds it for one operand.  The distributed step takes the minimum of this over all
+// ranks' blocks: the reference's leading run (algorithm.hpp:272-275) is a property of the whole matrix.
+__global__ void k_first_key_raw(const int32_t *major, const int32_t *minor, const double *val, size_t n, int minor_bits, int major_bits, int swap,
+	unsigned long long *first_key)
+{
+	unsigned long long best = ~0ull;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const double v = val[i];
+		if (v != 0 && v == v) {
+			const uint64_t key = ((uint64_t)(uint32_t)major[i] << minor_bits) | (uint64_t)(uint32_t)minor[i];
+			const unsigned long long k = ref_key(key, minor_bits, major_bits, swap);
+			best = k < best ? k : best;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(best, d, 64); best = o < best ? o : best; }
+	if (lane_id() == 0 && best != ~0ull) atomicMin(first_key, best);
+}
+
+void first_kept_key_raw(spsamd_ctx *c, const spsamd_coo *Xdev, int lead, int ref_lead, unsigned long long *out_dev)
+{
+	SPS_HIP(hipMemsetAsync(out_dev, 0xFF, sizeof(unsigned long long), c->stream));
+	const size_t n = Xdev->nnz;
+	if (!n) return;
+	const uint64_t shape[2] = {Xdev->shape0, Xdev->shape1};
+	const int mb = bits_for(shape[1 - lead]), Mb = bits_for(shape[lead]);
+	const int32_t *major = lead == 0 ? Xdev->idx0 : Xdev->idx1, *minor = lead == 0 ? Xdev->idx1 : Xdev->idx0;
+	k_first_key_raw<<<dim3(std::min(grid_for(n), 2048u)), dim3(256), 0, c->stream>>>(major, minor, Xdev->val, n, mb, Mb, ref_lead != lead ? 1 : 0, out_dev);
+	SPS_LAUNCH_CHECK();
 }
 
 uint32_t *sorted_permutation(spsamd_ctx *c, const spsamd_coo *X, int lead)
@@ -373,10 +433,11 @@ __global__ void k_rowptr_ends(const int32_t *row, uint32_t n, uint64_t nptr, uin
 	else if (r > (uint64_t)(uint32_t)row[n - 1]) ptr[r] = n;
 }
 
-uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra)
+uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra, uint32_t *into)
 {
 	uint64_t nptr = m.nrow + 1 + extra;
-	uint32_t *ptr = c->arena.get<uint32_t>(nptr);
+	uint32_t *ptr = into ? into : c->arena.get<uint32_t>(nptr);
+	if (!m.nnz) { fill_zero(c, ptr, nptr * sizeof(uint32_t)); return ptr; }
 	if (m.nnz && nptr <= 8ull * m.nnz + 1024) {
 		k_rowptr_ends<<<dim3(grid_for(nptr)), dim3(256), 0, c->stream>>>(m.row, m.nnz, nptr, ptr);
 		SPS_LAUNCH_CHECK();

@@ -163,6 +163,8 @@ T read_back(spsamd_ctx *c, const T *dev)
 
 // ---------------------------------------------------------------- consolidated operand (consolidate.hip)
 
+struct Prepared;
+
 // op(X) in row-major consolidated form on the device.
 struct ConMat {
 	int32_t *row = nullptr;     // leading (row of op(X)) index per tuple
@@ -172,13 +174,21 @@ struct ConMat {
 	uint64_t nrow = 0, ncol = 0;
 };
 
+// (spsamd_coo::mem == SPSAMD_MEM_PREPARED: idx0 carries the spsamd_operand handle, whose first member is its Prepared record)
+
 // Upload (if host) + consolidate `X` by sort order {lead, 1-lead} into `out`
-// (arena memory).  Mirrors Consolidate<> (algorithm.hpp:353-369): an operand
+// (arena memory).  A prepared operand whose lead matches yields its handle in *prep (otherwise null).  Mirrors Consolidate<> (algorithm.hpp:353-369): an operand
 // whose sort0 == lead is used as is.
 // `ref_lead` is the leading dimension of the order the REFERENCE consolidates this operand in
 // (it differs from `lead` for B: multiply_sparse.hpp:168); it decides which NaNs zero_nan drops.
 void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_lead, int duplicate_policy,
-	int zero_nan, ConMat *out);
+	int zero_nan, ConMat *out, Prepared **prep = nullptr, const unsigned long long *global_first_key = nullptr);
+// (global_first_key: the distributed step's -- device word holding the smallest reference-order key of a kept tuple over ALL
+// ranks' blocks; under zero_nan the NaNs below it are the leading run the reference drops, algorithm.hpp:272-275)
+
+// Distributed step under zero_nan: smallest reference-order key of a tuple of X (DEVICE arrays) that is neither 0 nor NaN
+// -> *out_dev (all ones: none).  Same key as consolidate_operand's own first-kept search.
+void first_kept_key_raw(spsamd_ctx *c, const spsamd_coo *Xdev, int lead, int ref_lead, unsigned long long *out_dev);
 
 // Row boundaries of a consolidated operand: dim_beginnings (algorithm.hpp:74-118):
 // beg[r] for each non-empty row + sentinel, and the row ids.
@@ -192,8 +202,47 @@ void dim_beginnings(spsamd_ctx *c, const ConMat &m, RowList *out);
 // Stable permutation sorting X by {lead, 1-lead} (device array of X->nnz uint32, arena memory).
 uint32_t *sorted_permutation(spsamd_ctx *c, const spsamd_coo *X, int lead);
 
-// Dense row pointer over all `nrow + extra` rows (extra trailing empty rows).
-uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra);
+// Dense row pointer over all `nrow + extra` rows (extra trailing empty rows); `into`: the array to fill (nrow + 1 + extra
+// entries) or null for arena memory.
+uint32_t *dense_rowptr(spsamd_ctx *c, const ConMat &m, uint32_t extra, uint32_t *into = nullptr);
+
+// One B tuple as the numeric kernels read it: column and value side by side (12 bytes), so
+// a short B segment sits in one or two cache lines instead of two partial lines of separate
+// col[] / val[] arrays.  Same bytes per product as the SoA form (12 B).
+struct __attribute__((packed, aligned(4))) BTup { int32_t col; uint32_t vlo, vhi; };
+
+// What a multiply derives from a consolidated operand before it can start, kept so that it is derived once: the reference
+// keeps an operand's row structure across calls as well (the lazy dim_beginnings cache, VectorCooArray.hpp:325-335) and
+// skips the consolidation of an operand that carries the wanted sort order (algorithm.hpp:360).  Either a VIEW for the
+// duration of one call (pieces in the context's arena; the distributed step hands its panel's row pointer in this way) or a
+// prepared-operand HANDLE of the C ABI (spsamd_operand_prepare: pieces in device memory of their own, built on first use).
+struct Prepared {
+	spsamd_ctx *ctx = nullptr;
+	ConMat m;                         // op(X), consolidated, row-major
+	int lead = 0;                     // the stored dimension that is m.row
+	bool owns = false;                // handle: the pieces are hipMalloc'ed and live until release()
+	std::vector<void *> owned;
+	uint64_t owned_bytes = 0;
+	// both roles
+	uint32_t *rowptr = nullptr;       // dense row pointer over nrow + 1 rows (the last one an empty sentinel): nrow + 2 entries
+	uint32_t maxlen = 0;              // longest row
+	bool have_maxlen = false;
+	// left operand
+	RowList rl;                       // dim_beginnings (algorithm.hpp:74-118)
+	bool have_rl = false;
+	// right operand
+	BTup *btup = nullptr;             // (col, val) interleaved, nnz + 4 entries
+	int W = 0;                        // column-window width of the heavy-row indices below (0: not built)
+	uint32_t nwin = 0, nwp = 0;
+	uint64_t nrowb = 0;
+	uint32_t *bwin = nullptr;         // [nrowb][nwin + 1] first tuple of row k with column >= w * W
+	uint16_t *wcnt = nullptr;         // [nrowb][nwp]      tuples of row k in window w
+	uint32_t *wptr = nullptr;         // [nwin][nrowb] + 1 window-major copy: CSR pointer per window ...
+	BTup *btw = nullptr;              // ... and its tuples
+	void *alloc(size_t bytes);        // arena memory of the current call (view) or device memory of the handle's own
+	template <class T> T *get(size_t n) { return (T *)alloc(n * sizeof(T)); }
+	void release();
+};
 
 // ---------------------------------------------------------------- multiply (spgemm.hip and the k_*.hip kernel files)
 
@@ -211,16 +260,21 @@ struct MultiplyArgs {
 	ScaleDev si, sj, sk;
 	ConMat A, B;
 	int sink_kind, sink_flags;
+	Prepared *pa = nullptr, *pb = nullptr;   // derived structures of A / B that already exist (or are kept once built): may be null
+	hipEvent_t b_ready = nullptr;            // the TUPLES of B arrive on another stream (the distributed step's panel): wait for this
+	                                         // event before the first kernel that reads them; its row pointer (pb->rowptr) is valid at once
 };
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res);
 
 // Shared body of the MM and MV entry points (capi.hip); `arena_ready`: the caller has reset the workspace
-// and may hold operands in it (the distributed step does).
+// and may hold operands in it (the distributed step does); `parts`: records of derived structures the caller already
+// has for A / B (the distributed step: its panel's row pointer, and the event that says the panel's tuples have arrived).
+struct OperandParts { Prepared *pa = nullptr, *pb = nullptr; hipEvent_t b_ready = nullptr; };
 int multiply_body(spsamd_ctx *c, double C,
 	const spsamd_vec *scalei, const spsamd_coo *A, char transpose_A,
 	const spsamd_vec *scalej, const spsamd_coo *B, char transpose_B,
 	const spsamd_vec *scalek, int duplicate_policy, int zero_nan,
-	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready);
+	int sink_kind, int sink_flags, spsamd_result *res, const char *what, bool arena_ready, const OperandParts *parts = nullptr);
 
 // Select the output set the next result is written to: the current one unless a device operand lives in it.
 void pick_output_set(spsamd_ctx *c, const spsamd_coo *const *operands, int n);

@@ -97,6 +97,28 @@ void DevBuf::release()
 	p = nullptr; cap = 0;
 }
 
+void *Prepared::alloc(size_t bytes)
+{
+	if (!owns) return ctx->arena.alloc(bytes);
+	bytes = round_up(bytes ? bytes : 1, 256);
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		throw Error{SPSAMD_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes for a prepared operand failed: " + hipGetErrorString(e)};
+	}
+	owned.push_back(p);
+	owned_bytes += bytes;
+	return p;
+}
+
+void Prepared::release()
+{
+	for (void *p : owned) (void)hipFree(p);
+	owned.clear();
+	owned_bytes = 0;
+}
+
 } // namespace spsamd
 
 void *spsamd_ctx::host_staging(size_t bytes)

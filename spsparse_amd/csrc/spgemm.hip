@@ -393,6 +393,65 @@ static void spgemm_all_light(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res,
 	res->ms_light = elapsed(c->ev[3], c->ev[4]);
 }
 
+// ---- derived structures of an operand: taken from its Prepared record where they exist, built (and kept there) otherwise
+static uint32_t *ensure_rowptr(spsamd_ctx *c, Prepared *p)
+{
+	// one empty sentinel row after the last: it receives the A tuples whose k is absent from scalej
+	if (!p->rowptr) p->rowptr = dense_rowptr(c, p->m, 1u, p->get<uint32_t>(p->m.nrow + 2));
+	return p->rowptr;
+}
+
+static void ensure_maxlen(spsamd_ctx *c, Prepared *pa, Prepared *pb)
+{
+	hipStream_t st = c->stream;
+	Prepared *need[2]; int n = 0;
+	if (!pa->have_maxlen) need[n++] = pa;
+	if (pb != pa && !pb->have_maxlen) need[n++] = pb;
+	if (!n) return;
+	uint32_t *mx = c->arena.get<uint32_t>(2);
+	fill_zero(c, mx, 2 * sizeof(uint32_t));
+	for (int q = 0; q < n; ++q) {
+		k_max_rowlen<<<dim3(std::min(grid_for(need[q]->m.nrow), 1024u)), dim3(256), 0, st>>>(need[q]->rowptr, need[q]->m.nrow, mx + q);
+		SPS_LAUNCH_CHECK();
+	}
+	struct { uint32_t a, b; } hm = read_back(c, (const decltype(hm) *)mx);
+	need[0]->maxlen = hm.a; need[0]->have_maxlen = true;
+	if (n > 1) { need[1]->maxlen = hm.b; need[1]->have_maxlen = true; }
+}
+
+static const RowList &ensure_rowlist(spsamd_ctx *c, Prepared *p)
+{
+	if (p->have_rl) return p->rl;
+	if (!p->owns) dim_beginnings(c, p->m, &p->rl);
+	else {
+		// a handle keeps its own copy (the arena's is gone after this call)
+		RowList tmp;
+		dim_beginnings(c, p->m, &tmp);
+		p->rl.nrows = tmp.nrows;
+		p->rl.beg = p->get<uint32_t>((size_t)tmp.nrows + 1);
+		p->rl.id = p->get<int32_t>(tmp.nrows ? tmp.nrows : 1);
+		SPS_HIP(hipMemcpyAsync(p->rl.beg, tmp.beg, ((size_t)tmp.nrows + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+		SPS_HIP(hipMemcpyAsync(p->rl.id, tmp.id, (size_t)tmp.nrows * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+	}
+	p->have_rl = true;
+	return p->rl;
+}
+
+static void wait_b_tuples(spsamd_ctx *c, MultiplyArgs &a)
+{
+	if (a.b_ready) { SPS_HIP(hipStreamWaitEvent(c->stream, a.b_ready, 0)); a.b_ready = nullptr; }
+}
+
+static BTup *ensure_btup(spsamd_ctx *c, MultiplyArgs &a, Prepared *p)
+{
+	if (p->btup) return p->btup;
+	wait_b_tuples(c, a);
+	p->btup = p->get<BTup>((size_t)p->m.nnz + DENSE_R);             // a dense-cell item reads R tuples: slack after the last one
+	k_pack_b<<<dim3(grid_for(p->m.nnz)), dim3(256), 0, c->stream>>>(p->m.col, p->m.val, p->m.nnz, p->btup);
+	SPS_LAUNCH_CHECK();
+	return p->btup;
+}
+
 static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 {
 	hipStream_t st = c->stream;
@@ -401,8 +460,16 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	if (A.nnz == 0 || B.nnz == 0) return;           // empty product (also SURVEY Appendix A.3)
 
 	SPS_HIP(hipEventRecord(c->ev[1], st));
-	const uint32_t extra = a.sj.present ? 1u : 0u;
-	uint32_t *bptr = dense_rowptr(c, B, extra);
+	// views for operands that come without a record of their own (pieces in this call's arena)
+	Prepared viewA, viewB;
+	viewA.ctx = viewB.ctx = c;
+	viewA.m = A; viewB.m = B;
+	const bool same = (a.pa && a.pa == a.pb) || (A.row == B.row && A.col == B.col && A.nnz == B.nnz && A.nrow == B.nrow);
+	Prepared *pa = a.pa ? a.pa : &viewA;
+	Prepared *pb = a.pb ? a.pb : (same ? pa : &viewB);
+	if (same && a.pb && !a.pa) pa = pb;
+	const uint32_t extra = 1u;                       // (the sentinel row: ensure_rowptr)
+	uint32_t *bptr = ensure_rowptr(c, pb);
 	const int32_t *acol = A.col;
 	const double *aval = A.val;
 	if (a.sj.present) {
@@ -414,23 +481,16 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	}
 	// ---- all rows light?  (longest A row) x (longest B row) <= 64: the direct kernel, no symbolic phase
 	if (!c->tune.light_path) {
-		const bool same = A.row == B.row && A.col == B.col && A.nnz == B.nnz && A.nrow == B.nrow;
-		const uint32_t *aptr = same ? bptr : dense_rowptr(c, A, 0);
-		uint32_t *mx = c->arena.get<uint32_t>(2);
-		fill_zero(c, mx, 2 * sizeof(uint32_t));
-		k_max_rowlen<<<dim3(std::min(grid_for(A.nrow), 1024u)), dim3(256), 0, st>>>(aptr, A.nrow, mx);
-		SPS_LAUNCH_CHECK();
-		if (!same) { k_max_rowlen<<<dim3(std::min(grid_for(B.nrow), 1024u)), dim3(256), 0, st>>>(bptr, B.nrow, mx + 1); SPS_LAUNCH_CHECK(); }
-		struct { uint32_t a, b; } hm = read_back(c, (const decltype(hm) *)mx);
-		if (same) hm.b = hm.a;
-		if ((uint64_t)hm.a * hm.b <= 64 && A.nrow < (uint64_t(1) << 32)) {
-			spgemm_all_light(c, a, res, aptr, acol, aval, bptr, (uint32_t)((uint64_t)hm.a * hm.b));
+		const uint32_t *aptr = pa == pb ? bptr : ensure_rowptr(c, pa);
+		ensure_maxlen(c, pa, pb);
+		if ((uint64_t)pa->maxlen * pb->maxlen <= 64 && A.nrow < (uint64_t(1) << 32)) {
+			wait_b_tuples(c, a);
+			spgemm_all_light(c, a, res, aptr, acol, aval, bptr, (uint32_t)((uint64_t)pa->maxlen * pb->maxlen));
 			return;
 		}
 	}
 	// ---- row structure of A (dim_beginnings)
-	RowList rl;
-	dim_beginnings(c, A, &rl);
+	const RowList rl = ensure_rowlist(c, pa);
 
 	// ---- symbolic: products per A tuple, per row, bins
 	uint32_t *elen = c->arena.get<uint32_t>(A.nnz);
@@ -482,9 +542,7 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	res->tuples_mid = hbc.tuples[5] + hbc.tuples[6] + hbc.tuples[7];
 	res->tuples_heavy = hbc.tuples[8];
 
-	BTup *btup = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);         // a dense-cell item reads R tuples: slack after the last one
-	k_pack_b<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.col, B.val, B.nnz, btup);
-	SPS_LAUNCH_CHECK();
+	BTup *btup = ensure_btup(c, a, pb);
 	RowMeta m{rl.beg, rl.id, acol, aval, bptr, btup, btup, elo, elen};
 #ifdef SPSAMD_ABLATIONS
 	set_ablation_word(c, c->tune.dbg);
@@ -506,7 +564,7 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	Heavy hv;
 	hv.n = bins.count[8];
 	hv.coo = coo;
-	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0, (a.sink_flags & SPSAMD_SINK_EXACT_PATTERN) != 0);
+	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0, (a.sink_flags & SPSAMD_SINK_EXACT_PATTERN) != 0, pb);
 	ep.wshift = hv.W == 8192 ? 13u : 14u;
 	uint32_t *segbase = nullptr;
 	int64_t nsegs = 0;
@@ -634,6 +692,7 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 	const ConMat &A = a.A, &B = a.B;
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
 	const uint32_t nblk = (uint32_t)((B.ncol + colblk - 1) / colblk);
+	wait_b_tuples(c, a);
 	struct BlockOut { int32_t *i = nullptr, *j = nullptr; double *v = nullptr; uint64_t n = 0; };
 	struct Blocks {                                                 // the blocks' COO outputs until they are interleaved
 		std::vector<BlockOut> b;
@@ -661,6 +720,8 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 		const uint32_t nb = read_back(c, off + B.nnz);
 		if (nb) {
 			MultiplyArgs as = a;
+			as.pb = nullptr;                                            // (B restricted to the block: nothing of B's record applies)
+			as.b_ready = nullptr;
 			as.B.row = c->arena.get<int32_t>(nb); as.B.col = c->arena.get<int32_t>(nb); as.B.val = c->arena.get<double>(nb);
 			as.B.nnz = nb; as.B.nrow = B.nrow; as.B.ncol = c1 - c0;
 			k_col_compact<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, flag, off, B.nnz, (uint32_t)c0, as.B.row, as.B.col, as.B.val);

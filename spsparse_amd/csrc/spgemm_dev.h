@@ -77,10 +77,7 @@ struct SinkParams {
 #define STAMP_COUNT(i) do { } while (0)
 #endif
 
-// One B tuple as the numeric kernels read it: column and value side by side (12 bytes), so
-// a short B segment sits in one or two cache lines instead of two partial lines of separate
-// col[] / val[] arrays.  Same bytes per product as the SoA form (12 B).
-struct __attribute__((packed, aligned(4))) BTup { int32_t col; uint32_t vlo, vhi; };
+// (BTup, one B tuple as the numeric kernels read it -- column and value side by side, 12 bytes -- is defined in internal.h)
 __device__ __forceinline__ double btup_val(const BTup &t) { return __hiloint2double((int)t.vhi, (int)t.vlo); }
 
 struct RowMeta {

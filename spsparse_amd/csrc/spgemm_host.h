@@ -77,7 +77,7 @@ template <int MODE> void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, cons
 
 // ---- the heavy rows' symbolic phase (symbolic_heavy.hip)
 void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
-	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern);
+	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern, Prepared *pb);
 void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase);
 
 #ifdef SPSAMD_ABLATIONS

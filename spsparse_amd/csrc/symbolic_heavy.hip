@@ -325,23 +325,23 @@ __global__ void k_gather_cells(const Cell *src, const uint32_t *perm, uint32_t n
 	if (i < n) dst[i] = src[perm[i]];
 }
 
-static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift, const uint16_t *wcnt, uint32_t nwp)
+static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32_t wshift, const uint16_t *wcnt, uint32_t nwp, Prepared *pb)
 {
 	hipStream_t st = c->stream;
 	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
 	uint16_t *cnt = c->arena.get<uint16_t>(total);
-	hv.wptr = c->arena.get<uint32_t>(total + 1);
+	hv.wptr = pb->get<uint32_t>(total + 1);
 	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(wcnt, (uint32_t)nrowb, hv.nwin, nwp, cnt);
 	SPS_LAUNCH_CHECK();
 	scan_exclusive_u16_u32(c, cnt, hv.wptr, total);
-	hv.btw = c->arena.get<BTup>((size_t)B.nnz + DENSE_R);
+	hv.btw = pb->get<BTup>((size_t)B.nnz + DENSE_R);
 	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
 	SPS_LAUNCH_CHECK();
 }
 
 // Heavy rows: window index of B, per-row window histogram, counting pass of the cell grouping.
 void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
-	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern)
+	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern, Prepared *pb)
 {
 	hipStream_t st = c->stream;
 	hv.W = B.ncol > (uint64_t(1) << 21) ? 16384 : 8192;
@@ -351,13 +351,16 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	if (hv.nwin > (uint32_t)WH_MAXW) throw TooWide{COLBLK};         // spgemm() then multiplies by column blocks of B
 	hv.nwin1 = hv.nwin + 1;
 	const uint64_t nrowb = B.nrow + extra;
-	{
+	// B's record already holds the indices for this window width (a prepared operand after its first multiply with heavy rows)
+	const bool have_index = pb->bwin && pb->W == hv.W && pb->nrowb == nrowb;
+	const bool have_wmajor = have_index && pb->wptr;
+	if (!have_index) {
 		// The window indices (bwin, its 16-bit counts, the window-major pointer with its counts, the heavy rows' histograms)
 		// grow with rows(B) x windows: 12 bytes per B row and window.  Where they would not fit what the device has left
 		// (or the cap a test sets), the product goes by column blocks narrow enough for them to fit.
 		const uint64_t per_window = nrowb * 12u + (uint64_t)hv.n * 4u;
 		uint64_t budget;
-		const uint64_t room = c->arena.slabs.empty() ? 0 : c->arena.slabs.back().cap - c->arena.slabs.back().used;
+		const uint64_t room = (pb->owns || c->arena.slabs.empty()) ? 0 : c->arena.slabs.back().cap - c->arena.slabs.back().used;
 		if (c->tune.index_budget_mb > 0) budget = (uint64_t)c->tune.index_budget_mb << 20;
 		else if (per_window * (hv.nwin + 1ull) <= room) budget = room;  // (the steady state: the workspace of an earlier call holds them)
 		else {
@@ -375,13 +378,19 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	}
 	hv.nrowb = nrowb;
 	hv.nnzb = B.nnz;
-	hv.bwin = c->arena.get<uint32_t>(nrowb * hv.nwin1);
 	hv.rows = bins.rows + bins.off[8];
 	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
 	const uint32_t nwp = (hv.nwin + 1u) & ~1u;
-	uint16_t *wcnt = c->arena.get<uint16_t>(nrowb * nwp);
-	k_bwin_build<<<dim3((unsigned)c->num_cu * 32u), dim3(256), 0, st>>>(B.col, bptr, nrowb, hv.nwin, nwp, wshift, hv.bwin, wcnt);
-	SPS_LAUNCH_CHECK();
+	if (!have_index) {
+		pb->bwin = pb->get<uint32_t>(nrowb * hv.nwin1);
+		pb->wcnt = pb->get<uint16_t>(nrowb * nwp);
+		pb->W = hv.W; pb->nwin = hv.nwin; pb->nwp = nwp; pb->nrowb = nrowb;
+		pb->wptr = nullptr; pb->btw = nullptr;
+		k_bwin_build<<<dim3((unsigned)c->num_cu * 32u), dim3(256), 0, st>>>(B.col, bptr, nrowb, hv.nwin, nwp, wshift, pb->bwin, pb->wcnt);
+		SPS_LAUNCH_CHECK();
+	}
+	hv.bwin = pb->bwin;
+	uint16_t *wcnt = pb->wcnt;
 	// The window-major copy of B needs only the index just built: it goes to the context's side stream now, beside the
 	// histograms, the cell grouping and their host round trips (a product with heavy rows almost always has dense cells; where
 	// it has none the copy was built for nothing).  The main stream waits for it before the numeric phase (SideJoin).
@@ -389,13 +398,15 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 		spsamd_ctx *c; bool on = false;
 		~SideJoin() { if (on) { (void)hipEventRecord(c->ev_side[1], c->side); (void)hipStreamWaitEvent(c->stream, c->ev_side[1], 0); } }
 	} side_join{c};
-	if (!c->tune.no_wmajor) {
+	if (!c->tune.no_wmajor && have_wmajor) { hv.wptr = pb->wptr; hv.btw = pb->btw; }
+	else if (!c->tune.no_wmajor) {
 		SPS_HIP(hipEventRecord(c->ev_side[0], st));
 		SPS_HIP(hipStreamWaitEvent(c->side, c->ev_side[0], 0));
 		side_join.on = true;                                        // from here on the main stream must wait for the side stream, whatever happens
 		c->stream = c->side;                                        // (the helpers launch on c->stream)
-		try { heavy_window_major(c, hv, B, wshift, wcnt, nwp); } catch (...) { c->stream = st; throw; }
+		try { heavy_window_major(c, hv, B, wshift, wcnt, nwp, pb); } catch (...) { c->stream = st; throw; }
 		c->stream = st;
+		pb->wptr = hv.wptr; pb->btw = hv.btw;
 	}
 	uint32_t *hubcount = c->arena.get<uint32_t>(1);
 	uint32_t *hublist = c->arena.get<uint32_t>(WH_HUB_MAX);

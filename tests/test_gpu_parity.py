@@ -368,33 +368,56 @@ def test_bench_dist_path_matches_plain_path():
         assert d["unit"] == "nnz(C)/s" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
-@pytest.mark.parametrize("wl_args", [["--scale", "16"], ["--workload", "poisson", "--grid", "512"]], ids=["rmat16", "poisson512"])
+@pytest.mark.parametrize("wl_args", [["--scale", "16"], ["--workload", "poisson", "--grid", "512"], ["--workload", "galerkin", "--grid", "64"]],
+                         ids=["rmat16", "poisson512", "galerkin64"])
 def test_bench_two_ranks_on_one_gpu(wl_args):
-    """The multi-rank control flow of bench.py with REAL second rank: two processes (torch.distributed.run),
-    both on cuda:0, collectives over gloo on host copies (--rehearse-gloo).  Distinct row blocks per rank,
-    calibration + rebalancing, panel exchange between different owners, digest reduction: the whole-job
-    digest must equal the single-GPU one."""
+    """The multi-rank control flow of bench.py with a REAL second rank, started the way the driver starts a scaling run --
+    the bare `python bench.py --gpus 2` (bench.py launches its own ranks) -- both on cuda:0, collectives over gloo on host
+    copies (--rehearse-gloo).  Distinct row blocks per rank, calibration + rebalancing, panel exchange between different
+    owners, digest reduction: the whole-job digest must equal the single-GPU one.  galerkin: BASELINE cfg5's two chained
+    products, the second with 'T' on B, cut at z planes (no remote rows for R*A, a one-plane halo for T*R^T)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    base = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + wl_args       # R-MAT: whole-block panels; stencil: exact panels
+    env.pop("WORLD_SIZE", None)
+    base = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-other-configs"] + wl_args       # R-MAT: whole-block panels; stencil: exact panels
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + base, cwd=root, env=env,
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-2000:]
     one = json.loads(p.stdout.strip().splitlines()[-1])
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29588", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--rehearse-gloo", "--calibrate", "2"] + base,
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--calibrate", "2"] + base,
                        cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-3000:]
     two = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["remote_panel_tuples"] > 0
     assert two["config"]["nnz_c"] == one["config"]["nnz_c"] and two["config"]["digest"]["hash"] == one["config"]["digest"]["hash"]
-    assert two["config"]["products"] == one["config"]["products"] and two["config"]["nnz_a"] == one["config"]["nnz_a"]
     assert abs(two["config"]["digest"]["sum"] - one["config"]["digest"]["sum"]) <= 1e-12 * abs(one["config"]["digest"]["sum"])
+    if "galerkin" in wl_args:
+        g = 64
+        assert two["config"]["nnz_c"] == 7 * (g // 2) ** 3 - 6 * (g // 2) ** 2
+        assert two["config"]["remote_panel_tuples"] == 2 * g * g          # one fine plane of R^T from the neighbour, each way
+        return
+    assert two["config"]["products"] == one["config"]["products"] and two["config"]["nnz_a"] == one["config"]["nnz_a"]
     assert len(two["config"]["calibration_local_ms"]) == 2 and len(two["config"]["calibration_local_ms"][0]) == 2
+
+
+def test_dist_multiply_two_ranks():
+    """spsamd_dist_multiply between two real ranks sharing this GPU (tests/dist_worker.py: the transport callback over gloo):
+    all of the reference's arguments ('T' flags, three scale vectors, C, DuplicatePolicy) on rectangular operands with
+    random cuts, zero_nan with NaNs, R-MAT whole-block panels, the Galerkin chain with 'T', and the agreement on errors
+    (a mis-cut block or a bad index on one rank: EINVAL there, EPEER on the other, and the communicator keeps working)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29591", os.path.join(root, "tests", "dist_worker.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "rank 0:" in p.stdout and "rank 1:" in p.stdout and "sharded cases ok" in p.stdout
 
 
 def test_dist_step_one_rank_rccl(ctx):
