@@ -17,7 +17,7 @@ def main(path):
     rows = cur.execute("select %s, start, end from kernels" % name_col).fetchall()
     agg = {}
     for name, s, e in rows:
-        short = re.sub(r"\(.*$", "", name)
+        short = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
         short = re.sub(r"^void ", "", short)
         a = agg.setdefault(short, [0, 0])
         a[0] += 1

@@ -40,10 +40,13 @@ extern "C" int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream)
 		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SPSAMD_EHIP; }
 		c->own_stream = true;
 	}
-	for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return SPSAMD_EHIP; }
-	for (auto &e : c->ev2) if (hipEventCreate(&e) != hipSuccess) { delete c; return SPSAMD_EHIP; }
-	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return SPSAMD_EHIP; }
-	for (auto &e : c->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return SPSAMD_EHIP; }
+	// (from here on a failure hands the context to spsamd_ctx_destroy, which releases whatever exists already)
+	for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
+	for (auto &e : c->ev2) if (hipEventCreate(&e) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
+	for (auto &e : c->ev_side) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
+	if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
+	for (auto &e : c->ev_side2) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
 	// developer knobs: the environment is consulted here and nowhere else
 	static const char *const knobs[] = {"window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path", "no_wmajor", "direct_min", "tiles_v1", "long_cap", "long_dense_min", "index_budget_mb", "trace"};
 	static const char *const envs[] = {"SPSAMD_W", "SPSAMD_CELL_CAP", "SPSAMD_DENSE_MIN", "SPSAMD_NO_TILES", "SPSAMD_XCD", "SPSAMD_EMIT_PATH", "SPSAMD_LIGHT_PATH", "SPSAMD_NO_WMAJOR", "SPSAMD_DIRECT_MIN", "SPSAMD_TILES_V1", "SPSAMD_LONG_CAP", "SPSAMD_LONG_DENSE_MIN", "SPSAMD_INDEX_BUDGET_MB", "SPSAMD_TRACE"};
@@ -74,8 +77,9 @@ extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize(c->stream);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->side) (void)hipStreamSynchronize(c->side);
+	if (c->side2) (void)hipStreamSynchronize(c->side2);
 	c->arena.release();
 	c->out[0].release(); c->out[1].release();
 	c->rowstat_n.release(); c->rowstat_s.release(); c->rowstat_h.release();
@@ -83,7 +87,9 @@ extern "C" void spsamd_ctx_destroy(spsamd_ctx *c)
 	for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : c->ev2) if (e) (void)hipEventDestroy(e);
 	for (auto &e : c->ev_side) if (e) (void)hipEventDestroy(e);
+	for (auto &e : c->ev_side2) if (e) (void)hipEventDestroy(e);
 	if (c->side) (void)hipStreamDestroy(c->side);
+	if (c->side2) (void)hipStreamDestroy(c->side2);
 	if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }

@@ -39,10 +39,17 @@ __global__ void k_inspect(const int32_t *major, const int32_t *minor, const doub
 			if (!(pc < c || (pc == c && pr < r))) f |= 4u;          // not STRICTLY in (minor, major) order either
 		}
 	}
+	// one update of the shared flag word per WORKGROUP (per wave, the reads of that one word were most of this kernel's
+	// time: 0.1 ms whatever the operand's size)
+	__shared__ uint32_t s_f;
+	if (threadIdx.x == 0) s_f = 0;
+	__syncthreads();
 	uint32_t wf = 0;
 #pragma unroll
 	for (uint32_t b = 1u; b <= 16u; b <<= 1) if (__ballot(f & b)) wf |= b;
-	if (wf && lane_id() == 0 && (*(volatile uint32_t *)flags & wf) != wf) atomicOr(flags, wf);
+	if (wf && lane_id() == 0) atomicOr(&s_f, wf);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_f && (*(volatile uint32_t *)flags & s_f) != s_f) atomicOr(flags, s_f);
 }
 
 __global__ void k_build_keys(const int32_t *major, const int32_t *minor, size_t n, int minor_bits, uint64_t *keys)
@@ -210,7 +217,7 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 
 	uint32_t *flags = c->arena.get<uint32_t>(2);
 	fill_zero(c, flags, 2 * sizeof(uint32_t));
-	k_inspect<<<dim3(std::min(grid_for(n), 8192u)), dim3(256), 0, c->stream>>>(major, minor, dv, n, out->nrow, out->ncol, zero_nan, flags);
+	k_inspect<<<dim3(std::min(grid_for(n, 1024), 2048u)), dim3(256), 0, c->stream>>>(major, minor, dv, n, out->nrow, out->ncol, zero_nan, flags);
 	SPS_LAUNCH_CHECK();
 	uint32_t f = read_back(c, flags);
 	if (f & 1u) throw Error{SPSAMD_EINVAL, "Sparse index out of bounds (VectorCooArray::add would reject it, VectorCooArray.hpp:246-262)"};

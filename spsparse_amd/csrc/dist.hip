@@ -176,21 +176,39 @@ __global__ void k_pack_rows(const int32_t *brow, const int32_t *bcol, const doub
 	dst.val[p][d] = bval[e];
 }
 
-// row index of every panel tuple, from the pointer's side: row k fills its own range (the row array is never sent).  A long
-// row is filled by its whole wave.
-__global__ void k_rows_from_ptr(const uint32_t *ptr, uint64_t nrow, int32_t *row)
+// row index of every panel tuple, from the pointer's side (the row array is never sent).  A wave takes 64 consecutive rows
+// and fills them one after the other, all lanes on the row at hand: coalesced stores whatever the rows' lengths.  Rows of
+// more than ROWS_LONG tuples go to a list that the second kernel fills a workgroup per row (the first 64 rows of an
+// un-permuted R-MAT hold a million tuples: left to their one wave they set the kernel's time, 0.1 ms).
+constexpr uint32_t ROWS_LONG = 2048;
+struct LongRow { uint32_t k, b, e, pad; };
+
+__global__ void k_rows_from_ptr(const uint32_t *ptr, uint64_t nrow, int32_t *row, LongRow *longlist, uint32_t *longcount)
 {
-	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t b = 0, e = 0;
-	if (k < nrow) { b = ptr[k]; e = ptr[k + 1]; }
-	if (e - b <= 32u) for (uint32_t t = b; t < e; ++t) row[t] = (int32_t)k;
-	uint64_t big = __ballot(e - b > 32u);
-	while (big) {                                                   // uniform
-		const int l = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)big) - 1);
-		big &= big - 1ull;
-		const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)b, l), ee = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
-		const int32_t kk = (int32_t)(k - lane_id() + (unsigned)l);
-		for (uint32_t t = bb + lane_id(); t < ee; t += 64u) row[t] = kk;
+	const uint64_t k0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull;
+	if (k0 >= nrow) return;                                          // (uniform)
+	const uint32_t start = ptr[min(k0 + lane_id(), nrow)];
+	const uint32_t stop = ptr[min(k0 + lane_id() + 1, nrow)];
+	unsigned long long todo = __ballot(stop > start);               // the non-empty rows of the 64
+	while (todo) {                                                   // uniform
+		const int l = __builtin_amdgcn_readfirstlane(__ffsll(todo) - 1);
+		todo &= todo - 1ull;
+		const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)start, l), e = (uint32_t)__builtin_amdgcn_readlane((int)stop, l);
+		const int32_t k = (int32_t)(k0 + (uint64_t)l);
+		if (e - b > ROWS_LONG) {
+			if (lane_id() == 0) longlist[atomicAdd(longcount, 1u)] = LongRow{(uint32_t)k, b, e, 0u};
+			continue;
+		}
+		for (uint32_t t = b + lane_id(); t < e; t += 64u) row[t] = k;
+	}
+}
+
+__global__ void k_rows_long(const LongRow *longlist, const uint32_t *longcount, int32_t *row)
+{
+	const uint32_t n = *longcount;
+	for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+		const LongRow r = longlist[item];
+		for (uint32_t t = r.b + threadIdx.x; t < r.e; t += blockDim.x) row[t] = (int32_t)r.k;
 	}
 }
 
@@ -506,7 +524,15 @@ void fetch_panel(spsamd_dist *d, const spsamd_coo *A_block, char transpose_A, co
 	P->pending = exchange(d, s, 2, true);
 	d->broken = false;
 	// (on the context's stream, beside the transfer: the panel's row array, which only the heavy-row indices read)
-	if (pn) { k_rows_from_ptr<<<dim3(grid_for(n_inner)), dim3(256), 0, st>>>(pptr, n_inner, prow); SPS_LAUNCH_CHECK(); }
+	if (pn) {
+		LongRow *longlist = c->arena.get<LongRow>((size_t)pn / ROWS_LONG + 1);
+		uint32_t *longcount = c->arena.get<uint32_t>(1);
+		fill_zero(c, longcount, sizeof(uint32_t));
+		k_rows_from_ptr<<<dim3(grid_for(n_inner)), dim3(256), 0, st>>>(pptr, n_inner, prow, longlist, longcount);
+		SPS_LAUNCH_CHECK();
+		k_rows_long<<<dim3(512), dim3(256), 0, st>>>(longlist, longcount, prow);
+		SPS_LAUNCH_CHECK();
+	}
 
 	*Aout = Ac;
 	P->m.row = prow; P->m.col = pcol; P->m.val = pval; P->m.nnz = pn;

@@ -110,7 +110,11 @@ struct spsamd_ctx {
 	hipEvent_t ev[10] = {};
 	hipEvent_t ev2[3] = {};                  // around the tile launches of the heavy rows
 	hipStream_t side = nullptr;              // second stream: the window-major copy of B is built on it beside the rest of the symbolic phase
-	hipEvent_t ev_side[2] = {};              // [0] main -> side (inputs ready), [1] side -> main (copy built)
+	hipEvent_t ev_side[2] = {};              // [0] main -> side (inputs ready), [1] side -> main (copy built: waited for just before the dense cells)
+	hipStream_t side2 = nullptr;             // third stream: the cell lists are sorted on it beside the light and mid rows' kernels
+	hipEvent_t ev_side2[2] = {};             // [0] main -> side2 (cells emitted), [1] side2 -> main (lists sorted: waited for before the heavy rows' kernels)
+	bool wm_pending = false, sort_pending = false;   // work of this call still running on side / side2 that the main stream has not waited for yet
+	void join_side(bool wm, bool sort);      // make the main stream wait for it (no-op where nothing is pending)
 	int num_cu = 256;
 	void *host_staging(size_t bytes);
 };

@@ -121,6 +121,12 @@ void Prepared::release()
 
 } // namespace spsamd
 
+void spsamd_ctx::join_side(bool wm, bool sort)
+{
+	if (wm && wm_pending) { wm_pending = false; (void)hipStreamWaitEvent(stream, ev_side[1], 0); }
+	if (sort && sort_pending) { sort_pending = false; (void)hipStreamWaitEvent(stream, ev_side2[1], 0); }
+}
+
 void *spsamd_ctx::host_staging(size_t bytes)
 {
 	if (bytes > pinned_cap) {

@@ -82,7 +82,8 @@ __device__ __forceinline__ int bin_of(uint32_t P)
 // Per non-empty A row: product count and bin.  scalei (multiply_sparse.hpp:195
 // and the Join2 of ScaledMultXiter :79-86): a row absent from the vector, or
 // whose scale is 0, is skipped.
-constexpr int CLS_ITEMS = 16;                   // rows per thread: few workgroups -> few same-address global atomics
+constexpr int CLS_ITEMS = 4;                    // rows per thread: fewer workgroups -> fewer same-address global atomics, but the rows of a thread
+                                                // are a chain of dependent loads (16: 78 us for the 68 K rows of a 1/8 block of cfg2 -- 17 workgroups)
 
 __global__ __launch_bounds__(256) void k_classify(const uint32_t *beg, const int32_t *id, uint32_t nrows, const int64_t *pref, const uint32_t *elen,
 	const int32_t *si_pos, const double *si_val, uint32_t *rprod, uint8_t *rbin, BinCounters *bc)
@@ -189,8 +190,13 @@ __global__ void k_max_rowlen(const uint32_t *ptr, uint64_t nrow, uint32_t *out)
 	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrow; r += (uint64_t)gridDim.x * blockDim.x) v = max(v, ptr[r + 1] - ptr[r]);
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-	// (same-address atomics serialise: only a wave that would raise the maximum issues one)
-	if (lane_id() == 0 && v > *(volatile uint32_t *)out) atomicMax(out, v);
+	// (same-address atomics serialise: one per workgroup, and only where it would raise the maximum)
+	__shared__ uint32_t s_v;
+	if (threadIdx.x == 0) s_v = 0;
+	__syncthreads();
+	if (lane_id() == 0 && v) atomicMax(&s_v, v);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_v > *(volatile uint32_t *)out) atomicMax(out, s_v);
 }
 
 // Cells for the mid rows (P_r <= 4096): the whole row, no window index.
@@ -243,6 +249,7 @@ __global__ void k_digest_reduce(const DigestSlot *slots, DigestSlot *out, const 
 template <int MODE>
 static void launch_heavy_hash(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk)
 {
+	c->join_side(hv.ntile2 != 0, true);                             // the sorted lists (and, for direct cells, the window-major copy)
 	SPS_HIP(hipEventRecord(c->ev2[0], c->stream));
 	if (hv.ntile && hv.tiles2 == 0) launch_tiles_bm<MODE>(c, hv, m, ep, sk);
 	else if (hv.ntile && hv.tiles2 == 2) launch_tiles_hash2<MODE>(c, hv, m, ep, sk);
@@ -411,7 +418,7 @@ static void ensure_maxlen(spsamd_ctx *c, Prepared *pa, Prepared *pb)
 	uint32_t *mx = c->arena.get<uint32_t>(2);
 	fill_zero(c, mx, 2 * sizeof(uint32_t));
 	for (int q = 0; q < n; ++q) {
-		k_max_rowlen<<<dim3(std::min(grid_for(need[q]->m.nrow), 1024u)), dim3(256), 0, st>>>(need[q]->rowptr, need[q]->m.nrow, mx + q);
+		k_max_rowlen<<<dim3(std::min(grid_for(need[q]->m.nrow, 1024), 1024u)), dim3(256), 0, st>>>(need[q]->rowptr, need[q]->m.nrow, mx + q);
 		SPS_LAUNCH_CHECK();
 	}
 	struct { uint32_t a, b; } hm = read_back(c, (const decltype(hm) *)mx);
@@ -561,8 +568,12 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
 	uint32_t *nseg = c->arena.get<uint32_t>(rl.nrows);
 	fill_u32(c, nseg, 1u, rl.nrows);
+	// work this call puts on the context's other streams is waited for by the main stream before the first kernel that needs
+	// it -- and before the call ends, whatever happens (its buffers are this call's workspace)
+	struct SideGuard { spsamd_ctx *c; ~SideGuard() { c->join_side(true, true); } } side_guard{c};
 	Heavy hv;
 	hv.n = bins.count[8];
+	hv.tuples = hbc.tuples[8];
 	hv.coo = coo;
 	if (hv.n) heavy_prepare(c, hv, bins, m, B, bptr, extra, nseg, (a.sink_flags & SPSAMD_SINK_ORDERED) != 0, (a.sink_flags & SPSAMD_SINK_EXACT_PATTERN) != 0, pb);
 	ep.wshift = hv.W == 8192 ? 13u : 14u;
@@ -611,8 +622,10 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		SPS_HIP(hipEventRecord(c->ev[4], st));
 		launch_mid<MODE_DIGEST>(c, bins, mc, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[5], st));
+		if (hv.n) heavy_sort_lists(c, hv);
 		launch_heavy_hash<MODE_DIGEST>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[6], st));
+		c->join_side(true, true);
 		launch_heavy_dense<MODE_DIGEST>(c, hv, m, ep, sk);
 		SPS_HIP(hipEventRecord(c->ev[8], st));
 		k_digest_reduce<<<dim3(1), dim3(64), 0, st>>>(slots, slots + DIGEST_SLOTS, sk.err);
@@ -633,7 +646,9 @@ static void spgemm_once(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res)
 		SPS_HIP(hipEventRecord(c->ev[3], st));
 		launch_light<MODE_COUNT>(c, bins, m, ep, sk);
 		launch_mid<MODE_COUNT>(c, bins, mc, m, ep, sk);
+		if (hv.n) heavy_sort_lists(c, hv);
 		launch_heavy_hash<MODE_COUNT>(c, hv, m, ep, sk);
+		c->join_side(true, true);
 		launch_heavy_dense<MODE_COUNT>(c, hv, m, ep, sk);
 		scan_exclusive_u32_i64(c, segcount, segoff, (size_t)nsegs);
 		int64_t reserved = read_back(c, segoff + nsegs);

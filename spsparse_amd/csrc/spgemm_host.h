@@ -21,6 +21,7 @@ constexpr uint64_t COLBLK = (uint64_t)2048 << 14;                   // 2048 wind
 
 struct Heavy {
 	uint32_t n = 0;                  // heavy rows
+	uint64_t tuples = 0;             // ... and their A tuples
 	uint32_t *rows = nullptr;
 	uint32_t *bwin = nullptr;
 	uint32_t nwin = 0, nwin1 = 0;
@@ -79,6 +80,7 @@ template <int MODE> void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, cons
 void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m, const ConMat &B, const uint32_t *bptr,
 	uint32_t extra, uint32_t *nseg, bool ordered, bool pattern, Prepared *pb);
 void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase);
+void heavy_sort_lists(spsamd_ctx *c, Heavy &hv);
 
 #ifdef SPSAMD_ABLATIONS
 void set_ablation_word(spsamd_ctx *c, int word);          // k_hash.hip (the only unit that reads it through ABLG)

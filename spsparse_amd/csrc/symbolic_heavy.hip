@@ -25,32 +25,65 @@ __global__ void k_xcd_bounds(const int64_t *pref, uint32_t n, uint32_t *xb)
 
 // Window index of B: bwin[k * (nwin+1) + w] = first tuple of B row k whose column is >= w * W (bwin[k][0] = bptr[k],
 // bwin[k][nwin] = bptr[k+1]), and the tuples of row k in window w as 16 bits (<= W <= 16384: half the bytes of the offset
-// pairs for the histogram below, which reads one whole row of that table per A tuple of a heavy row; rows padded to an
-// even number of entries, nwp, so that two windows are read as one 32-bit word).
-// Both tables in one pass, one thread per (B row, window): bwin[k][w] = first tuple of row k with column >= w * W -- a
-// binary search in the row's (short, cached) columns -- and the window's tuple count from a second search that starts
-// there (0.6 ms at scale 20, like the prefill + per-tuple fill + counting pass it replaced: one kernel instead of three).
-__global__ __launch_bounds__(256) void k_bwin_build(const int32_t *bcol, const uint32_t *bptr, uint64_t nrowb, uint32_t nwin, uint32_t nwp, uint32_t wshift,
-	uint32_t *bwin, uint16_t *cnt)
+// pairs for the histogram below, which reads one whole row of that table per A tuple of a heavy row; rows padded to a
+// multiple of eight entries, nwp, so that eight windows are read as one aligned 16-byte word).
+// Built from the TUPLES' side in two balanced passes, nothing searched.  (1) Counts: the tuples are walked 64 per wave; the
+// last lane of every run of equal (row, window) adds the run's length to the row's 16-bit count (a pair of counts per 32-bit
+// word: one global atomic per run and wave -- the hub rows of an R-MAT hold runs of hundreds).  (2) Index: a workgroup per
+// tile of consecutive rows loads the tile's count rows into LDS, a wave per row scans them from the row's pointer and
+// writes the index row whole.  (Before: one thread per (row, window) and two binary searches each, 0.55 ms at scale 20 -- a
+// third of what a rank of a sharded run spends outside its numeric kernels.  Tried on the way: a wave per row walking its
+// tuples, 0.73 ms -- a chain of dependent loads per row; counting in an LDS table per tile of rows, 1.16 ms -- the tile of
+// an R-MAT's first 256 rows holds 2.5 M tuples.)
+constexpr int BT_NT = 256;
+constexpr size_t BT_LDS = 36 * 1024;         // a tile's count rows (rows x nwp x 2 bytes) and row pointers: four workgroups per CU
+
+__global__ __launch_bounds__(BT_NT) void k_wcnt_count(const int32_t *brow, const int32_t *bcol, uint32_t nnzb, uint32_t wshift, uint32_t nwp, uint32_t *wcnt32)
 {
-	const uint32_t nwin1 = nwin + 1u;
-	const uint64_t total = nrowb * nwin1, stride = (uint64_t)gridDim.x * blockDim.x;
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-		const uint64_t k = i / nwin1;
-		const uint32_t w = (uint32_t)(i - k * nwin1);
-		const uint32_t lo = bptr[k], hi = bptr[k + 1];
-		auto lower = [&](uint32_t l, uint64_t target) {             // first tuple in [l, hi) whose column is >= target
-			uint32_t h = hi;
-			while (l < h) {
-				const uint32_t mid = l + ((h - l) >> 1);
-				if ((uint64_t)(uint32_t)bcol[mid] < target) l = mid + 1; else h = mid;
-			}
-			return l;
-		};
-		const uint32_t v = w == nwin ? hi : lower(lo, (uint64_t)w << wshift);
-		bwin[i] = v;
-		if (w < nwin) cnt[k * nwp + w] = (uint16_t)(lower(v, ((uint64_t)w + 1u) << wshift) - v);
-		else if (nwin < nwp) cnt[k * nwp + nwin] = 0;               // (the padding entry of an odd window count)
+	const uint32_t lane = lane_id();
+	const uint32_t nchunk = (nnzb + 63u) >> 6, nwaves = gridDim.x * (BT_NT / 64);
+	for (uint32_t ch = blockIdx.x * (BT_NT / 64) + wave_id(); ch < nchunk; ch += nwaves) {      // uniform per wave
+		const uint32_t e = (ch << 6) + lane;
+		const bool valid = e < nnzb;
+		const unsigned long long key = valid ? (unsigned long long)(uint32_t)brow[e] * nwp + ((uint32_t)bcol[e] >> wshift) : ~0ull;
+		const unsigned long long kprev = __shfl_up(key, 1, 64), knext = __shfl_down(key, 1, 64);
+		const bool is_start = valid && (lane == 0 || key != kprev);
+		const bool is_end = valid && (lane == 63 || key != knext);
+		const unsigned long long sm = __ballot(is_start);
+		if (is_end) {
+			const unsigned long long upto = sm & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+			const uint32_t first = 63u - (uint32_t)__clzll((long long)upto);       // this run's first lane
+			atomicAdd(&wcnt32[key >> 1], (lane - first + 1u) << ((uint32_t)(key & 1ull) << 4));    // (nwp is even: the key's parity is the window's)
+		}
+	}
+}
+
+__global__ __launch_bounds__(BT_NT) void k_bwin_scan(const uint16_t *wcnt, const uint32_t *bptr, uint64_t nrowb, uint32_t tr, uint32_t nwin, uint32_t nwp,
+	uint32_t *bwin)
+{
+	extern __shared__ uint32_t s_dyn[];                              // [tr][nwp / 2] packed pairs of counts, then [tr] row pointers
+	const uint32_t nwin1 = nwin + 1u, lane = lane_id(), wv = wave_id(), nph = nwp >> 1;
+	const uint64_t k0 = (uint64_t)blockIdx.x * tr;
+	const uint32_t rows = (uint32_t)std::min<uint64_t>(tr, nrowb - k0);
+	uint32_t *s_ptr = s_dyn + (size_t)tr * nph;
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(wcnt + k0 * nwp);       // the tile's rows are contiguous, 16-byte multiples
+		uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
+		for (uint32_t i = threadIdx.x; i < (rows * nph) >> 2; i += BT_NT) dst[i] = src[i];
+		for (uint32_t r = threadIdx.x; r < rows; r += BT_NT) s_ptr[r] = bptr[k0 + r];
+	}
+	__syncthreads();
+	for (uint32_t r = wv; r < rows; r += BT_NT / 64) {              // a wave per row: lane = window
+		const uint32_t *src = s_dyn + r * nph;
+		uint32_t carry = s_ptr[r];
+		uint32_t *bw = bwin + (k0 + r) * nwin1;
+		for (uint32_t c0 = 0; c0 < nwin1; c0 += 64u) {
+			const uint32_t w = c0 + lane;
+			const uint32_t v = w < nwin ? (src[w >> 1] >> ((w & 1u) << 4)) & 0xFFFFu : 0u;
+			const uint32_t inc = wave_inclusive_scan_u32(v);
+			if (w < nwin1) bw[w] = carry + inc - v;
+			carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+		}
 	}
 }
 
@@ -62,21 +95,106 @@ __global__ __launch_bounds__(256) void k_bwin_build(const int32_t *bcol, const u
 // with a CSR row pointer per window: wptr[w * nrowb + k] .. [+1].  The working set of the
 // workgroups that are on window w is then |B_w| * 12 bytes plus a 4 * nrowb byte pointer slice,
 // and a row's pass over its A tuples (ascending k) moves forward through both.
-__global__ __launch_bounds__(256) void k_wm_counts(const uint16_t *wcnt, uint32_t nrowb, uint32_t nwin, uint32_t nwp, uint16_t *cnt)
+//
+// wptr[w][k] = (tuples of the windows before w) + (tuples of window w in the rows before k): a prefix sum DOWN THE COLUMNS
+// of the row-major count table, written transposed.  Three kernels over tiles of WM_TR rows: column sums per tile; per
+// column the scan of the tile sums (and the windows' bases); per tile the column prefixes inside it, through LDS, stored
+// along k.  (Before: the table was transposed, 0.38 ms, the 134 M transposed counts were scanned like any array, 0.45 ms.)
+constexpr int WM_TR = 256;                   // rows per tile
+constexpr int WM_CS = 72;                    // columns of a tile in LDS at a time (x WM_TR x 2 bytes = 36 KB: four workgroups per CU)
+constexpr int WM_NT = 256;
+
+__global__ __launch_bounds__(WM_NT) void k_wm_tile_sums(const uint16_t *wcnt, uint64_t nrowb, uint32_t nwp, uint32_t ntile, uint32_t *tilesum)
 {
-	// transposes the 16-bit counts of k_bwin_build (row-major, nwp per row) into window-major order through LDS (reading the
-	// counts instead of differencing the 32-bit index halves the bytes read)
-	__shared__ uint16_t tile[64][66];
-	const uint32_t k0 = blockIdx.x * 64u, w0 = blockIdx.y * 64u;
-	const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
-	for (uint32_t ky = ty; ky < 64; ky += 4) {
-		const uint32_t k = k0 + ky;
-		if (k < nrowb && w0 + tx < nwin) tile[ky][tx] = wcnt[(uint64_t)k * nwp + w0 + tx];
+	extern __shared__ uint32_t s_dyn[];                              // nwp column sums
+	const uint32_t nq = nwp >> 3;                                    // 16-byte words per row
+	for (uint32_t w = threadIdx.x; w < nwp; w += WM_NT) s_dyn[w] = 0;
+	__syncthreads();
+	const uint64_t k0 = (uint64_t)blockIdx.x * WM_TR;
+	const uint32_t rows = (uint32_t)std::min<uint64_t>(WM_TR, nrowb - k0);
+	const uint4 *tab = reinterpret_cast<const uint4 *>(wcnt + k0 * nwp);      // rows are 16-byte multiples
+	uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t myq = 0xFFFFFFFFu;
+	// the tile is rows * nq consecutive 16-byte words; a thread keeps to ONE column group (its word index mod nq is fixed
+	// when the stride is a multiple of nq)
+	const uint32_t stride = (WM_NT / nq) * nq;                       // (nq <= 256)
+	if (threadIdx.x < stride) {
+		myq = threadIdx.x % nq;
+		for (uint32_t i = threadIdx.x; i < rows * nq; i += stride) {
+			const uint4 x = tab[i];
+			acc[0] += x.x & 0xFFFFu; acc[1] += x.x >> 16; acc[2] += x.y & 0xFFFFu; acc[3] += x.y >> 16;
+			acc[4] += x.z & 0xFFFFu; acc[5] += x.z >> 16; acc[6] += x.w & 0xFFFFu; acc[7] += x.w >> 16;
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) if (acc[u]) atomicAdd(&s_dyn[myq * 8u + u], acc[u]);
 	}
 	__syncthreads();
-	for (uint32_t wy = ty; wy < 64; wy += 4) {
-		const uint32_t w = w0 + wy, k = k0 + tx;
-		if (w < nwin && k < nrowb) cnt[(uint64_t)w * nrowb + k] = tile[tx][wy];
+	for (uint32_t w = threadIdx.x; w < nwp; w += WM_NT) tilesum[(uint64_t)w * ntile + blockIdx.x] = s_dyn[w];
+}
+
+// one workgroup per window: exclusive scan of its tile sums, in place; the window's total
+__global__ __launch_bounds__(WM_NT) void k_wm_tile_scan(uint32_t *tilesum, uint32_t ntile, uint32_t *wtot)
+{
+	__shared__ uint32_t scratch[WM_NT / 64 + 1];
+	uint32_t *a = tilesum + (uint64_t)blockIdx.x * ntile;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < ntile; base += WM_NT) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < ntile ? a[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_exclusive_scan<uint32_t, WM_NT>(v, scratch, &tot);
+		if (i < ntile) a[i] = carry + ex;
+		carry += tot;
+	}
+	if (threadIdx.x == 0) wtot[blockIdx.x] = carry;
+}
+
+// the windows' bases (exclusive scan of their totals, one workgroup) and the pointer's end sentinel
+__global__ __launch_bounds__(WM_NT) void k_wm_bases(const uint32_t *wtot, uint32_t nwin, uint32_t *wbase, uint32_t *wptr_end)
+{
+	__shared__ uint32_t scratch[WM_NT / 64 + 1];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nwin; base += WM_NT) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < nwin ? wtot[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_exclusive_scan<uint32_t, WM_NT>(v, scratch, &tot);
+		if (i < nwin) wbase[i] = carry + ex;
+		carry += tot;
+	}
+	if (threadIdx.x == 0) *wptr_end = carry;
+}
+
+__global__ __launch_bounds__(WM_NT) void k_wm_ptr(const uint16_t *wcnt, uint64_t nrowb, uint32_t nwin, uint32_t nwp, uint32_t ntile,
+	const uint32_t *tileoff, const uint32_t *wbase, uint32_t *wptr)
+{
+	__shared__ uint16_t s_t[WM_TR * WM_CS];
+	const uint32_t tile = blockIdx.x, lane = lane_id(), wv = wave_id();
+	const uint64_t k0 = (uint64_t)tile * WM_TR;
+	const uint32_t rows = (uint32_t)std::min<uint64_t>(WM_TR, nrowb - k0);
+	for (uint32_t c0 = 0; c0 < nwin; c0 += WM_CS) {                 // column slabs of the tile
+		const uint32_t ncs = std::min<uint32_t>(WM_CS, nwp - c0);    // (a multiple of 8)
+		const uint32_t nq = ncs >> 3;
+		if (c0) __syncthreads();
+		for (uint32_t i = threadIdx.x; i < rows * nq; i += WM_NT) {
+			const uint32_t r = i / nq, q = i - r * nq;
+			const uint4 x = *reinterpret_cast<const uint4 *>(wcnt + (k0 + r) * nwp + c0 + q * 8u);
+			*reinterpret_cast<uint4 *>(&s_t[r * WM_CS + q * 8u]) = x;
+		}
+		__syncthreads();
+		const uint32_t ncol = std::min<uint32_t>(ncs, nwin - c0);
+		for (uint32_t c = wv; c < ncol; c += WM_NT / 64) {          // a wave per column: lane = row
+			const uint32_t w = c0 + c;
+			uint32_t run = wbase[w] + tileoff[(uint64_t)w * ntile + tile];
+#pragma unroll
+			for (uint32_t ch = 0; ch < WM_TR / 64; ++ch) {
+				const uint32_t r = ch * 64u + lane;
+				const uint32_t v = r < rows ? (uint32_t)s_t[r * WM_CS + c] : 0u;
+				const uint32_t inc = wave_inclusive_scan_u32(v);
+				if (r < rows) wptr[(uint64_t)w * nrowb + k0 + r] = run + inc - v;
+				run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+			}
+		}
 	}
 }
 
@@ -92,84 +210,85 @@ __global__ void k_wm_scatter(const int32_t *brow, const int32_t *bcol, const dou
 	out[dst] = t;
 }
 
-// Per heavy row: products per column window.  One workgroup per row; a thread owns a PAIR of
-// windows (one 32-bit load per A tuple), sub-groups of threads take different tuples and every
-// thread keeps 8 tuples in flight.  A row's workgroup takes at most WH_HUB tuples; rows with more
-// are noted in a list and their remaining tuples are dealt in parts to a second launch that adds
-// into the row's histogram with global atomics (the longest hub row -- tens of thousands of tuples
-// -- would otherwise set the time of the whole kernel).
+// Per heavy row: products per column window.  A thread owns a PAIR of windows (one 32-bit load per A tuple), sub-groups
+// of threads take different tuples and every thread keeps 8 tuples in flight: a workgroup's time is the round trips of its
+// tuples' loads, so no workgroup takes more than WH_PART tuples -- the row's own workgroup its first WH_PART, the rest go, part
+// by part, into a work list for a second launch that adds into the row's histogram with global atomics.  (With 4096 tuples
+// per workgroup both launches took as long as their longest row: 0.47 + 0.25 ms on a 1/8 block of cfg2, 1.6 + 0.4 ms on the whole.)
 constexpr int WH_NT = 256;
 constexpr int WH_MAXW = 2048;                // windows supported (ncol <= 2^25 at W = 16384)
-constexpr uint32_t WH_HUB = 4096;            // tuples one workgroup takes
-constexpr uint32_t WH_HUB_MAX = 65536;       // list capacity (rows beyond it are finished by their own workgroup)
+constexpr uint32_t WH_PART = 512;            // tuples one workgroup takes
+
+struct HubItem { uint32_t h, part; };
 
 __device__ __forceinline__ void win_hist_span(const RowMeta &m, const uint16_t *wcnt, uint32_t nwp, uint32_t beg, uint32_t end, uint32_t *s_cnt)
 {
-	const uint32_t npair = nwp >> 1;
-	const uint32_t *tab = (const uint32_t *)wcnt;                       // row k: npair words
-	uint32_t ppad = 1;
-	while (ppad < npair && ppad < WH_NT) ppad <<= 1;
-	const uint32_t nsub = ppad < WH_NT ? WH_NT / ppad : 1;
-	const uint32_t sub = threadIdx.x / ppad, p0 = threadIdx.x % ppad;
-	for (uint32_t p = p0; p < npair; p += ppad) {                       // one pass unless there are more than 256 pairs
-		uint32_t c0 = 0, c1 = 0;
-		uint32_t e = beg + sub;
-		for (; e + 7 * nsub < end; e += 8 * nsub) {
-			uint32_t x[8];
+	// a thread owns EIGHT windows (one aligned 16-byte load per A tuple); the workgroup's threads form WH_NT / nq groups that
+	// take different tuples, four in flight each
+	const uint32_t nq = nwp >> 3;                                       // 16-byte words per row of the table (<= 256)
+	const uint4 *tab = reinterpret_cast<const uint4 *>(wcnt);
+	const uint32_t nsub = WH_NT / nq;
+	const uint32_t sub = threadIdx.x / nq, q = threadIdx.x - sub * nq;
+	if (sub >= nsub) return;
+	uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto add = [&](const uint4 &x) {
+		acc[0] += x.x & 0xFFFFu; acc[1] += x.x >> 16; acc[2] += x.y & 0xFFFFu; acc[3] += x.y >> 16;
+		acc[4] += x.z & 0xFFFFu; acc[5] += x.z >> 16; acc[6] += x.w & 0xFFFFu; acc[7] += x.w >> 16;
+	};
+	uint32_t e = beg + sub;
+	for (; e + 3 * nsub < end; e += 4 * nsub) {
+		uint4 x[4];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) x[u] = tab[(uint64_t)m.acol[e + u * nsub] * npair + p];
+		for (int u = 0; u < 4; ++u) x[u] = tab[(uint64_t)(uint32_t)m.acol[e + u * nsub] * nq + q];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { c0 += x[u] & 0xFFFFu; c1 += x[u] >> 16; }
-		}
-		for (; e < end; e += nsub) { const uint32_t x = tab[(uint64_t)m.acol[e] * npair + p]; c0 += x & 0xFFFFu; c1 += x >> 16; }
-		if (c0) atomicAdd(&s_cnt[2 * p], c0);
-		if (c1) atomicAdd(&s_cnt[2 * p + 1], c1);
+		for (int u = 0; u < 4; ++u) add(x[u]);
 	}
+	for (; e < end; e += nsub) add(tab[(uint64_t)(uint32_t)m.acol[e] * nq + q]);
+#pragma unroll
+	for (int u = 0; u < 8; ++u) if (acc[u]) atomicAdd(&s_cnt[q * 8u + u], acc[u]);
 }
 
 __global__ __launch_bounds__(WH_NT) void k_win_hist(const uint32_t *hrows, uint32_t nheavy, RowMeta m, const uint16_t *wcnt,
-	uint32_t nwin, uint32_t nwp, uint32_t *winprod, uint32_t *hubcount, uint32_t *hublist)
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, uint32_t *hubcount, HubItem *hublist, uint32_t hubcap)
 {
 	__shared__ uint32_t s_cnt[WH_MAXW];
-	__shared__ uint32_t s_listed;
+	__shared__ uint32_t s_slot, s_parts;
 	const uint32_t h = blockIdx.x, r = hrows[h];
 	const uint32_t beg = m.beg[r], end = m.beg[r + 1];
 	for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
 	if (threadIdx.x == 0) {
-		uint32_t listed = 0;
-		if (end - beg > WH_HUB) {
-			const uint32_t slot = atomicAdd(hubcount, 1u);
-			if (slot < WH_HUB_MAX) { hublist[slot] = h; listed = 1; }
+		uint32_t parts = 0, slot = 0;
+		if (end - beg > WH_PART) {
+			parts = (end - beg - 1) / WH_PART;                          // parts 1 .. of the row
+			slot = atomicAdd(hubcount, parts);
+			if (slot + parts > hubcap) parts = 0;                       // (cannot happen: the list holds sum(len / WH_PART) entries; then the row is this workgroup's)
 		}
-		s_listed = listed;
+		s_slot = slot; s_parts = parts;
 	}
 	__syncthreads();
-	win_hist_span(m, wcnt, nwp, beg, s_listed ? beg + WH_HUB : end, s_cnt);
+	const uint32_t parts = s_parts;
+	for (uint32_t i = threadIdx.x; i < parts; i += WH_NT) hublist[s_slot + i] = HubItem{h, i + 1};
+	win_hist_span(m, wcnt, nwp, beg, parts ? beg + WH_PART : end, s_cnt);
 	__syncthreads();
 	for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) winprod[(uint64_t)h * nwin + w] = s_cnt[w];
 }
 
-// The tuples beyond WH_HUB of the listed rows, WH_HUB at a time: work item = (listed row, part).
+// The parts beyond the first of the long rows: work item = (row, part).
 __global__ __launch_bounds__(WH_NT) void k_win_hist_hub(const uint32_t *hrows, RowMeta m, const uint16_t *wcnt,
-	uint32_t nwin, uint32_t nwp, uint32_t *winprod, const uint32_t *hubcount, const uint32_t *hublist)
+	uint32_t nwin, uint32_t nwp, uint32_t *winprod, const uint32_t *hubcount, const HubItem *hublist, uint32_t hubcap)
 {
 	__shared__ uint32_t s_cnt[WH_MAXW];
-	const uint32_t nhub = min(*hubcount, WH_HUB_MAX);
-	// items are enumerated row by row; a workgroup finds its items by walking the (short) list
-	uint32_t item = 0;
-	for (uint32_t q = 0; q < nhub; ++q) {
-		const uint32_t h = hublist[q], r = hrows[h];
-		const uint32_t beg = m.beg[r] + WH_HUB, end = m.beg[r + 1];
-		const uint32_t parts = (end - beg + WH_HUB - 1) / WH_HUB;
-		for (uint32_t part = 0; part < parts; ++part, ++item) {
-			if (item % gridDim.x != blockIdx.x) continue;                 // uniform
-			for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
-			__syncthreads();
-			win_hist_span(m, wcnt, nwp, beg + part * WH_HUB, min(end, beg + (part + 1) * WH_HUB), s_cnt);
-			__syncthreads();
-			for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) { const uint32_t v = s_cnt[w]; if (v) atomicAdd(&winprod[(uint64_t)h * nwin + w], v); }
-			__syncthreads();
-		}
+	const uint32_t nitem = min(*hubcount, hubcap);
+	for (uint32_t item = blockIdx.x; item < nitem; item += gridDim.x) {     // uniform
+		const HubItem it = hublist[item];
+		const uint32_t r = hrows[it.h];
+		const uint32_t beg = m.beg[r] + it.part * WH_PART, end = min(m.beg[r + 1], beg + WH_PART);
+		for (uint32_t w = threadIdx.x; w < nwp; w += WH_NT) s_cnt[w] = 0;
+		__syncthreads();
+		win_hist_span(m, wcnt, nwp, beg, end, s_cnt);
+		__syncthreads();
+		for (uint32_t w = threadIdx.x; w < nwin; w += WH_NT) { const uint32_t v = s_cnt[w]; if (v) atomicAdd(&winprod[(uint64_t)it.h * nwin + w], v); }
+		__syncthreads();
 	}
 }
 
@@ -329,11 +448,18 @@ static void heavy_window_major(spsamd_ctx *c, Heavy &hv, const ConMat &B, uint32
 {
 	hipStream_t st = c->stream;
 	const uint64_t nrowb = hv.nrowb, total = nrowb * hv.nwin;
-	uint16_t *cnt = c->arena.get<uint16_t>(total);
+	const uint32_t ntile = (uint32_t)((nrowb + WM_TR - 1) / WM_TR);
 	hv.wptr = pb->get<uint32_t>(total + 1);
-	k_wm_counts<<<dim3((unsigned)((nrowb + 63) / 64), (hv.nwin + 63) / 64), dim3(256), 0, st>>>(wcnt, (uint32_t)nrowb, hv.nwin, nwp, cnt);
+	uint32_t *tilesum = c->arena.get<uint32_t>((uint64_t)nwp * ntile);
+	uint32_t *wtot = c->arena.get<uint32_t>(hv.nwin), *wbase = c->arena.get<uint32_t>(hv.nwin);
+	k_wm_tile_sums<<<dim3(ntile), dim3(WM_NT), nwp * sizeof(uint32_t), st>>>(wcnt, nrowb, nwp, ntile, tilesum);
 	SPS_LAUNCH_CHECK();
-	scan_exclusive_u16_u32(c, cnt, hv.wptr, total);
+	k_wm_tile_scan<<<dim3(hv.nwin), dim3(WM_NT), 0, st>>>(tilesum, ntile, wtot);
+	SPS_LAUNCH_CHECK();
+	k_wm_bases<<<dim3(1), dim3(WM_NT), 0, st>>>(wtot, hv.nwin, wbase, hv.wptr + total);
+	SPS_LAUNCH_CHECK();
+	k_wm_ptr<<<dim3(ntile), dim3(WM_NT), 0, st>>>(wcnt, nrowb, hv.nwin, nwp, ntile, tilesum, wbase, hv.wptr);
+	SPS_LAUNCH_CHECK();
 	hv.btw = pb->get<BTup>((size_t)B.nnz + DENSE_R);
 	k_wm_scatter<<<dim3(grid_for(B.nnz)), dim3(256), 0, st>>>(B.row, B.col, B.val, B.nnz, wshift, hv.bwin, hv.nwin1, hv.wptr, nrowb, hv.btw);
 	SPS_LAUNCH_CHECK();
@@ -380,40 +506,47 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	hv.nnzb = B.nnz;
 	hv.rows = bins.rows + bins.off[8];
 	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
-	const uint32_t nwp = (hv.nwin + 1u) & ~1u;
+	const uint32_t nwp = (hv.nwin + 7u) & ~7u;
 	if (!have_index) {
 		pb->bwin = pb->get<uint32_t>(nrowb * hv.nwin1);
 		pb->wcnt = pb->get<uint16_t>(nrowb * nwp);
 		pb->W = hv.W; pb->nwin = hv.nwin; pb->nwp = nwp; pb->nrowb = nrowb;
 		pb->wptr = nullptr; pb->btw = nullptr;
-		k_bwin_build<<<dim3((unsigned)c->num_cu * 32u), dim3(256), 0, st>>>(B.col, bptr, nrowb, hv.nwin, nwp, wshift, pb->bwin, pb->wcnt);
+		fill_zero(c, pb->wcnt, nrowb * nwp * sizeof(uint16_t));
+		k_wcnt_count<<<dim3((unsigned)c->num_cu * 16u), dim3(BT_NT), 0, st>>>(B.row, B.col, B.nnz, wshift, nwp, reinterpret_cast<uint32_t *>(pb->wcnt));
+		SPS_LAUNCH_CHECK();
+		// tile rows: as many as the LDS budget holds (128 at 136 windows, 32 at 512, 8 at 2048)
+		uint32_t tr = 256;
+		while (tr > 4 && (size_t)tr * (nwp * 2 + 4) > BT_LDS) tr >>= 1;
+		static bool lds_attr = false;                               // (more than the default 64 KB of dynamic LDS)
+		if (!lds_attr) { SPS_HIP(hipFuncSetAttribute((const void *)k_bwin_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BT_LDS)); lds_attr = true; }
+		k_bwin_scan<<<dim3((unsigned)((nrowb + tr - 1) / tr)), dim3(BT_NT), (size_t)tr * (nwp * 2 + 4), st>>>(pb->wcnt, bptr, nrowb, tr, hv.nwin, nwp, pb->bwin);
 		SPS_LAUNCH_CHECK();
 	}
 	hv.bwin = pb->bwin;
 	uint16_t *wcnt = pb->wcnt;
 	// The window-major copy of B needs only the index just built: it goes to the context's side stream now, beside the
-	// histograms, the cell grouping and their host round trips (a product with heavy rows almost always has dense cells; where
-	// it has none the copy was built for nothing).  The main stream waits for it before the numeric phase (SideJoin).
-	struct SideJoin {
-		spsamd_ctx *c; bool on = false;
-		~SideJoin() { if (on) { (void)hipEventRecord(c->ev_side[1], c->side); (void)hipStreamWaitEvent(c->stream, c->ev_side[1], 0); } }
-	} side_join{c};
+	// histograms, the cell grouping, their host round trips and the numeric kernels that do not read it (a product with heavy
+	// rows almost always has dense cells; where it has none the copy was built for nothing).  The main stream waits for it just
+	// before the dense cells' kernel (spsamd_ctx::join_side) -- or, whatever happens, before the call ends (spgemm_once).
 	if (!c->tune.no_wmajor && have_wmajor) { hv.wptr = pb->wptr; hv.btw = pb->btw; }
 	else if (!c->tune.no_wmajor) {
 		SPS_HIP(hipEventRecord(c->ev_side[0], st));
 		SPS_HIP(hipStreamWaitEvent(c->side, c->ev_side[0], 0));
-		side_join.on = true;                                        // from here on the main stream must wait for the side stream, whatever happens
+		c->wm_pending = true;                                       // from here on the main stream must wait for the side stream before this call ends, whatever happens
 		c->stream = c->side;                                        // (the helpers launch on c->stream)
-		try { heavy_window_major(c, hv, B, wshift, wcnt, nwp, pb); } catch (...) { c->stream = st; throw; }
+		try { heavy_window_major(c, hv, B, wshift, wcnt, nwp, pb); } catch (...) { c->stream = st; (void)hipEventRecord(c->ev_side[1], c->side); throw; }
 		c->stream = st;
+		SPS_HIP(hipEventRecord(c->ev_side[1], c->side));
 		pb->wptr = hv.wptr; pb->btw = hv.btw;
 	}
 	uint32_t *hubcount = c->arena.get<uint32_t>(1);
-	uint32_t *hublist = c->arena.get<uint32_t>(WH_HUB_MAX);
+	const uint32_t hubcap = (uint32_t)(hv.tuples / WH_PART) + 1u;     // sum over the heavy rows of (tuples - 1) / WH_PART fits
+	HubItem *hublist = c->arena.get<HubItem>(hubcap);
 	fill_zero(c, hubcount, sizeof(uint32_t));
-	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
+	k_win_hist<<<dim3(hv.n), dim3(WH_NT), 0, st>>>(hv.rows, hv.n, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist, hubcap);
 	SPS_LAUNCH_CHECK();
-	k_win_hist_hub<<<dim3((unsigned)c->num_cu * 4u), dim3(WH_NT), 0, st>>>(hv.rows, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist);
+	k_win_hist_hub<<<dim3((unsigned)c->num_cu * 8u), dim3(WH_NT), 0, st>>>(hv.rows, m, wcnt, hv.nwin, nwp, hv.winprod, hubcount, hublist, hubcap);
 	SPS_LAUNCH_CHECK();
 	for (int k = 0; k < NCLS; ++k) {
 		hv.cnt.base[k] = c->arena.get<uint32_t>(hv.n);
@@ -422,7 +555,12 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	if (c->tune.cell_cap >= 64 && c->tune.cell_cap <= (int)CELL_CAP) hv.cell_cap = (uint32_t)c->tune.cell_cap;
 	if (c->tune.dense_min >= 64 && c->tune.dense_min <= (int)CELL_CAP) hv.dense_min = (uint32_t)c->tune.dense_min;
 	// (a window between dense_min and cell_cap products becomes a dense cell; smaller ones are grouped up to cell_cap)
-	unsigned long long *clsprod = c->arena.get<unsigned long long>(NCLS + 2);
+	// everything the counting pass accumulates into sits in ONE block, zeroed by one memset (they were eleven)
+	const size_t hn4 = ((size_t)hv.n + 3) & ~(size_t)3;
+	uint32_t *zblock = c->arena.get<uint32_t>(4 * hn4 + 2 * (NCLS + 2) + 4);
+	const size_t zbytes = (4 * hn4 + 2 * (NCLS + 2) + 4) * sizeof(uint32_t);
+	unsigned long long *clsprod = reinterpret_cast<unsigned long long *>(zblock + 4 * hn4);
+	unsigned long long *alt_block = clsprod + NCLS + 2;
 	hv.tb.enabled = !c->tune.no_tiles;
 	// Tile kernel of the hash-class cells: 0 bitmap rank (k_bm_tiles) | 1 first generation | 2 hash tiles v2.
 	// ORDERED runs on the first generation (the variant that exists), EXACT_PATTERN on the bitmap tiles or the hash tiles v2;
@@ -456,13 +594,15 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	hv.direct_min = c->tune.direct_min > 0 ? (uint32_t)c->tune.direct_min : DIRECT_MIN_DEFAULT;
 	hv.tb2.enabled = hv.tb.enabled && !c->tune.no_wmajor && !ordered && !pattern && hv.direct_min < hv.dense_min;
 	hv.tb2.pb = (uint32_t)hv.W;      // items of a direct tile: one bit each in a W-bit bitmap
-	for (TileBases *t : {&hv.tb, &hv.tb2}) {
-		t->ntc = c->arena.get<uint32_t>(hv.n); t->ntl = c->arena.get<uint32_t>(hv.n);
-		t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
+	{
+		int q = 0;
+		for (TileBases *t : {&hv.tb, &hv.tb2}) {
+			t->ntc = zblock + hn4 * q++; t->ntl = zblock + hn4 * q++;
+			t->tcbase = c->arena.get<uint32_t>((size_t)hv.n + 1); t->tlbase = c->arena.get<uint32_t>((size_t)hv.n + 1);
+		}
 	}
 	auto count_pass = [&]() {
-		fill_zero(c, clsprod, (NCLS + 2) * sizeof(unsigned long long));
-		for (TileBases *t : {&hv.tb, &hv.tb2}) { fill_zero(c, t->ntc, hv.n * sizeof(uint32_t)); fill_zero(c, t->ntl, hv.n * sizeof(uint32_t)); }
+		fill_zero(c, zblock, zbytes);
 		k_cells<false><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nseg, hv.base, CellLists{}, nullptr, clsprod, tile_kinds(hv));
 		SPS_LAUNCH_CHECK();
 	};
@@ -475,8 +615,7 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 		// pass of the bitmap scheme also counts the cells the hash scheme would cut; only where that one wins is it repeated.
 		set_scheme(0);
 		hv.alt_cap = (uint32_t)(TILE_T / 2); hv.alt_span = 0;
-		hv.alt_cells = c->arena.get<unsigned long long>(2);          // [0] cells of the hash scheme, [1] of the bitmap scheme
-		fill_zero(c, hv.alt_cells, 2 * sizeof(unsigned long long));
+		hv.alt_cells = alt_block;                                    // [0] cells of the hash scheme, [1] of the bitmap scheme (zeroed with the rest)
 		count_pass();
 		WordList wl; wl.add64(hv.alt_cells); wl.add64(hv.alt_cells + 1);
 		uint32_t hw[4];
@@ -509,8 +648,6 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *segbase)
 {
 	hipStream_t st = c->stream;
-	int wbits = 1;                                   // bits of a window index: the cell lists are sorted on as few digits as needed
-	while ((1u << wbits) < hv.nwin) ++wbits;
 	CellLists lists;
 	for (int k = 0; k < NCLS; ++k) { hv.cells[k] = c->arena.get<Cell>(hv.ncell[k] ? hv.ncell[k] : 1); lists.list[k] = hv.cells[k]; }
 	hv.tb.tcells = c->arena.get<TCell>(hv.ntcell ? hv.ntcell : 1);
@@ -519,6 +656,27 @@ void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *seg
 	hv.tb2.tiles = c->arena.get<Tile>(hv.ntile2 ? hv.ntile2 : 1);
 	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, tile_kinds(hv));
 	SPS_LAUNCH_CHECK();
+	SPS_HIP(hipEventRecord(c->ev_side2[0], st));
+}
+
+// The lists are put in window-major order by some fifty small launches -- a quarter of a millisecond of launch latency
+// whatever the lists' sizes, host and device alike -- that nothing but the heavy rows' kernels waits for.  The driver
+// (spgemm_once) calls this AFTER it has enqueued the light and mid rows' kernels, and the launches go to the context's third
+// stream: the device sorts beside those kernels while the host is still enqueueing; the main stream joins before the first
+// kernel that walks a list.
+void heavy_sort_lists(spsamd_ctx *c, Heavy &hv)
+{
+	hipStream_t st = c->stream;
+	int wbits = 1;                                   // bits of a window index: the cell lists are sorted on as few digits as needed
+	while ((1u << wbits) < hv.nwin) ++wbits;
+	SPS_HIP(hipStreamWaitEvent(c->side2, c->ev_side2[0], 0));       // (recorded after the cells were emitted)
+	c->sort_pending = true;
+	struct OnSide2 {
+		spsamd_ctx *c; hipStream_t main;
+		~OnSide2() { c->stream = main; (void)hipEventRecord(c->ev_side2[1], c->side2); }
+	} on_side2{c, st};
+	c->stream = c->side2;
+	st = c->side2;
 	for (int kd = 0; kd < 2; ++kd) {
 		TileBases &t = kd ? hv.tb2 : hv.tb;
 		const uint32_t nd = kd ? hv.ntile2 : hv.ntile;
