@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02/ (scratch, written by scripts/collect_profiles.sh on the GPU box) -> profiles/r02/ (tracked):
+"""gpurun_out/$ROUND/ (scratch, written by scripts/collect_profiles.sh on the GPU box) -> gpurun_out/$ROUND/summary/ (small:
+travels back; copied to profiles/$ROUND/, tracked):
 per-kernel summaries of every kernel trace, the PMC passes of the headline bench per kernel, pmc_traffic.json
 (what bench.py's roofline.traffic quotes) and the bench lines printed under the profiler."""
 import csv
@@ -14,12 +15,13 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
-DST = os.path.join(ROOT, "profiles", "r02")
+ROUND = os.environ.get("ROUND", "r03")
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
+DST = os.path.join(SRC, "summary")
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
     return re.sub(r"^void ", "", name)
 
 
@@ -65,6 +67,13 @@ def main():
         b = os.path.join(SRC, "bench_%s.json" % name)
         if os.path.exists(b):
             shutil.copy(b, os.path.join(DST, "%s_bench_under_rocprof.json" % name))
+    blk = glob.glob(os.path.join(SRC, "trace_block", "**", "*_results.db"), recursive=True)
+    if blk:
+        with open(os.path.join(DST, "block_step_timeline.txt"), "w") as f:
+            subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "step_timeline.py"), blk[0]], stdout=f)
+        lg = os.path.join(SRC, "block.log")
+        if os.path.exists(lg):
+            shutil.copy(lg, os.path.join(DST, "block_rehearsal.log"))
     # PMC passes: per-kernel sums per launch
     per = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
@@ -87,7 +96,7 @@ def main():
                 if cnt[k].get(c):
                     grp[g][c] += v[c] / cnt[k][c]            # every kernel of a group runs once per bench step
     try:
-        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        commit = os.environ.get("COMMIT") or subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         commit = "?"
     j = {"command": "python3 bench.py --steps 2 --warmup 1 --no-other-configs --no-cpu-baseline", "commit": commit,

@@ -450,6 +450,66 @@ def test_dist_step_one_rank_rccl(ctx):
         d.close()
 
 
+def test_prepared_operands_equal_plain_ones(ctx):
+    """spsamd_operand_prepare: an operand consolidated once, its row structure / packed tuples / window indices built by the
+    first product that needs them and kept (the reference's Consolidate<> fast path and lazy dim_beginnings cache,
+    algorithm.hpp:360, VectorCooArray.hpp:325-335).  Results equal the plain operand's in every sink, on both sides, with
+    scale vectors and 'T'; the second product with the same handle does not rebuild what the first one built."""
+    from spsparse_amd import capi
+    a = wl.rmat(14, seed=6)                                   # duplicates, heavy rows, dense and hash cells
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    s, keep = capi.host_coo(*a)
+    op = capi.Operand(ctx, s, '.', capi.AS_A | capi.AS_B)
+    try:
+        assert op.coo.mem == capi.MEM_PREPARED and op.coo.nnz < a[0].size        # duplicates were merged once, here
+        b0 = op.bytes
+        r1 = ctx.multiply(op.coo, op.coo, sink=capi.SINK_COO, flags=capi.SINK_ORDERED)
+        _check(ctx.fetch(r1), want, exact=True)
+        b1 = op.bytes
+        assert b1 > b0                                        # the heavy rows' indices were built into the handle ...
+        d1 = ctx.multiply(op.coo, op.coo, sink=capi.SINK_DIGEST)
+        assert op.bytes == b1                                 # ... once
+        cnt, ssum, h = orc.digest(*want[:3])
+        assert (d1.nnz, d1.hash) == (cnt, h) and abs(d1.sum - ssum) <= REL * abs(ssum)
+        assert d1.ms_consolidate < 0.5 and d1.nnz_a == op.coo.nnz
+        plain = ctx.multiply(s, s, sink=capi.SINK_DIGEST)
+        assert d1.ms_symbolic < plain.ms_symbolic             # nothing of B's indices is rebuilt
+        # one side prepared, the other plain; scale vectors; C != 1
+        rng = np.random.default_rng(3)
+        n = a[3][0]
+        si, sj, sk = _rand_vec(rng, n), _rand_vec(rng, n), _rand_vec(rng, n)
+        w2 = orc.multiply(A, A, 2.5, si, '.', sj, '.', sk, rowwise=True, nthreads=8)
+        vs = [capi.host_vec(v.idx, v.val, v.shape0) for v in (si, sj, sk)]
+        for X, Y in ((op.coo, s), (s, op.coo)):
+            r = ctx.multiply(X, Y, 2.5, vs[0][0], '.', vs[1][0], '.', vs[2][0], sink=capi.SINK_COO, flags=capi.SINK_ORDERED)
+            _check(ctx.fetch(r), w2, exact=True)
+        # used with the OTHER transpose flag than it was prepared for: read as a device operand sorted the other way
+        w3 = orc.multiply(A, A, 1.0, None, 'T', None, '.', None, rowwise=True, nthreads=8)
+        r3 = ctx.multiply(op.coo, op.coo, tA='T', sink=capi.SINK_COO, flags=capi.SINK_ORDERED)
+        _check(ctx.fetch(r3), w3, exact=True)
+        # the stand-alone algorithms take it too
+        assert np.array_equal(ctx.dim_beginnings(op.coo, 0), orc.dim_beginnings(orc.consolidate(a[0], a[1], a[2], 0)[0]))
+    finally:
+        op.close()
+    # rectangular, prepared for 'T' on the right: the Galerkin product's R^T (cfg5) -- no sort of R per product
+    g = 16
+    R3, A3 = wl.aggregation3d(g), wl.laplace3d(g)
+    sR, k1 = capi.host_coo(*R3, sort0=0); sA, k2 = capi.host_coo(*A3, sort0=0)
+    wt = orc.multiply(orc.Mat(*R3), orc.Mat(*A3), rowwise=True)
+    wc = orc.multiply(orc.Mat(wt[0], wt[1], wt[2], wt[3]), orc.Mat(*R3), tB='T', rowwise=True)
+    Rt = capi.Operand(ctx, sR, 'T', capi.AS_B)
+    try:
+        rt = ctx.multiply(sR, sA, sink=capi.SINK_COO)
+        rc = ctx.multiply(capi.result_operand(rt), Rt.coo, tB='T', sink=capi.SINK_COO)
+        _check(ctx.fetch(rc), wc, exact=True)
+    finally:
+        Rt.close()
+    # under zero_nan an operand is prepared for ONE side (the two sides drop different NaNs)
+    with pytest.raises(capi.SpsamdError):
+        capi.Operand(ctx, s, '.', capi.AS_A | capi.AS_B, zero_nan=True)
+
+
 def test_two_contexts_on_two_threads(ctx):
     """SURVEY 8b 'Threading': the library must be callable concurrently on different handles.
     Two host threads, one context (HIP stream, arena) each, multiply different operands at once."""
