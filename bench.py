@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--grid", type=int, default=0, help="mesh size of --workload poisson (cfg3 = 4096) / galerkin (cfg5 = 256)")
     ap.add_argument("--sink", choices=["digest", "coo"], default="digest", help="N=1: the sink of the timed multiply")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--prepared", action="store_true",
+                    help="N=1: the operands are prepared once before the timed steps (spsamd_operand_prepare); not the headline, "
+                         "which starts from the raw tuples every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="N=1: only the headline workload")
     ap.add_argument("--cpu-scale", type=int, default=15, help="R-MAT scale of the bounded CPU sample (scale 15: ~25 s on one core)")
@@ -124,8 +127,9 @@ def cpu_baseline(scale, seed):
 class Workload:
     """Device-resident operands of one BASELINE config and its step."""
 
-    def __init__(self, torch, capi, ctx, dev, kind, scale=20, grid=0, seed=1, sink="digest"):
+    def __init__(self, torch, capi, ctx, dev, kind, scale=20, grid=0, seed=1, sink="digest", prepared=False):
         self.torch, self.capi, self.ctx, self.kind = torch, capi, ctx, kind
+        self.handles = []
         self.sink = capi.SINK_COO if sink == "coo" else capi.SINK_DIGEST
         self.sink_name = sink
 
@@ -169,17 +173,34 @@ class Workload:
                          "the COO sink, C = T*R^T reading T in place (chained result buffers), COO sink" % g)
             self.workspace = int(na * 260) + (512 << 20)
         torch.cuda.synchronize()
+        if prepared:
+            # every operand prepared ONCE (spsamd_operand_prepare): what a caller that multiplies with the same matrices again and
+            # again pays per product -- no inspection / consolidation / row pointers / window indices per step
+            def prep(coo, transpose, role):
+                h = capi.Operand(ctx, coo, transpose, role)
+                self.handles.append(h)
+                return h.coo
+            if kind == "galerkin":
+                self.Rt = prep(self.R, 'T', capi.AS_B)
+                self.R = prep(self.R, '.', capi.AS_A)
+                self.A = prep(self.A, '.', capi.AS_B)
+            else:
+                self.A = prep(self.A, '.', capi.AS_A | capi.AS_B)
+            self.name += ", operands prepared once (spsamd_operand_prepare)"
 
     def step(self):
         """One pass; returns the list of spsamd_result of its multiplies (one, or two for galerkin)."""
         capi, ctx = self.capi, self.ctx
         if self.kind == "galerkin":
             rt = ctx.multiply(self.R, self.A, sink=capi.SINK_COO)
-            rc = ctx.multiply(capi.result_operand(rt), self.R, tB="T", sink=capi.SINK_COO)
+            rc = ctx.multiply(capi.result_operand(rt), getattr(self, "Rt", self.R), tB="T", sink=capi.SINK_COO)
             return [rt, rc]
         return [ctx.multiply(self.A, self.A, sink=self.sink, flags=getattr(self, "flags", 0))]
 
     def release(self):
+        for h in self.handles:
+            h.close()
+        self.handles = []
         self.t = self.t2 = None
         self.torch.cuda.empty_cache()
 
@@ -221,33 +242,6 @@ def run_workload(torch, w, steps, warmup):
     if w.sink_name == "digest":
         out["digest"] = {"sum": float(last[0].sum), "hash": "%016x" % int(last[0].hash)}
     return out, results
-
-
-def prepared_run(torch, capi, dev, stream, scale, seed, steps=5, warmup=2):
-    """The headline product with its operand PREPARED once (spsamd_operand_prepare: consolidated tuples, row structure and --
-    built by the first product -- B's packed tuples and window indices, all kept in the handle): what a caller pays per
-    product when the same matrix takes part in many.  Never `value`: the headline starts from the raw tuples every step."""
-    c2 = capi.Context(dev.index, stream.cuda_stream)
-    try:
-        w = Workload(torch, capi, c2, dev, "rmat", scale=scale, seed=seed)
-        c2.reserve(w.workspace)
-        op = capi.Operand(c2, w.A, '.', capi.AS_A | capi.AS_B)
-        for _ in range(warmup):
-            c2.multiply(op.coo, op.coo, sink=capi.SINK_DIGEST)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r = c2.multiply(op.coo, op.coo, sink=capi.SINK_DIGEST)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        out = {"ms_per_step": ms, "steps": steps, "handle_GB": op.bytes / 1e9, "nnz_c": int(r.nnz),
-               "stage_ms": {"consolidate": r.ms_consolidate, "symbolic": r.ms_symbolic, "numeric": r.ms_numeric}}
-        op.close()
-        w.release()
-        return out
-    finally:
-        c2.close()
-        torch.cuda.empty_cache()
 
 
 def pcie_delivery(torch, capi, ctx, dev, scale, seed):
@@ -649,7 +643,7 @@ def headline(args, world, wname, n, ne, nnz_a, products, nnz_c, vsum, vhash, ms_
 
 def single_gpu(args, torch, capi, ctx, dev, stream):
     """N = 1: the headline workload, then (default run only) the other configs in the same process."""
-    w = Workload(torch, capi, ctx, dev, args.workload, args.scale, args.grid, args.seed, args.sink)
+    w = Workload(torch, capi, ctx, dev, args.workload, args.scale, args.grid, args.seed, args.sink, prepared=args.prepared)
     summary, results = run_workload(torch, w, args.steps, args.warmup)
     last = results[-1]
     flat = [r for step in results for r in step] if w.kind == "galerkin" else [step[0] for step in results]
@@ -673,7 +667,7 @@ def single_gpu(args, torch, capi, ctx, dev, stream):
     line["config"]["workspace_GB"] = summary["workspace_GB"]
     w.release()
     ctx.close()                                   # the headline's workspace goes back before the other configs run
-    default_line = args.workload == "rmat" and args.scale == 20 and args.sink == "digest"
+    default_line = args.workload == "rmat" and args.scale == 20 and args.sink == "digest" and not args.prepared
     if default_line and not args.no_other_configs:
         others = {}
 
@@ -694,11 +688,12 @@ def single_gpu(args, torch, capi, ctx, dev, stream):
         other("cfg5_galerkin256_coo", "galerkin", 5, 1, grid=256)
         other("cfg2_rmat20_coo_sink", "rmat", 2, 1, scale=20, seed=args.seed, sink="coo")
         other("cfg4_rmat23_one_gpu_digest", "rmat", 2, 1, scale=23, seed=args.seed)
-        try:
-            others["cfg2_prepared_operands_digest"] = prepared_run(torch, capi, dev, stream, args.scale, args.seed)
-            line["config"]["prepared_b_ms_per_step"] = others["cfg2_prepared_operands_digest"]["ms_per_step"]
-        except Exception as e:
-            others["cfg2_prepared_operands_digest"] = {"error": repr(e)}
+        # the same products with their operands prepared once (never `value`: the headline starts from the raw tuples every step)
+        other("cfg2_rmat20_digest_prepared", "rmat", 5, 2, scale=20, seed=args.seed, prepared=True)
+        other("cfg3_poisson4096_digest_prepared", "poisson", 10, 2, grid=4096, prepared=True)
+        other("cfg5_galerkin256_coo_prepared", "galerkin", 5, 1, grid=256, prepared=True)
+        if "ms_per_step" in others.get("cfg2_rmat20_digest_prepared", {}):
+            line["config"]["prepared_b_ms_per_step"] = others["cfg2_rmat20_digest_prepared"]["ms_per_step"]
         try:
             c3 = capi.Context(dev.index, stream.cuda_stream)
             others["pcie_inclusive_host_delivery"] = pcie_delivery(torch, capi, c3, dev, 17, args.seed)

@@ -178,10 +178,17 @@ int spsamd::multiply_body(spsamd_ctx *c, double C,
 	// (a prepared operand is taken as it was prepared, like any operand that carries the wanted sort order)
 	if (a0 == bk && same_operand(A, B) && (!zero_nan || hp)) { a.B = a.A; if (a.pa) a.pb = a.pa; }
 	else { consolidate_operand(c, B, bk, bj, duplicate_policy, zero_nan, &a.B, &hp); if (hp) a.pb = hp; }  // :188
+	if (sink_kind == SPSAMD_SINK_COO) c->own[c->cur_out].sort0 = -1;           // that set is about to be overwritten
 	upload_scale(c, scalei, ashape[a0], "scalei", &a.si);
 	upload_scale(c, scalej, ashape[a1], "scalej", &a.sj);
 	upload_scale(c, scalek, bshape[bj], "scalek", &a.sk);
 	spgemm(c, a, res);
+	if (sink_kind == SPSAMD_SINK_COO && res->idx0 && res->idx1) {
+		// row-major sorted, every (i, j) once, no zero: consolidated by sort order {0, 1} (read permuted: by {1, 0})
+		auto &o = c->own[c->cur_out];
+		o.d0 = permute ? res->idx1 : res->idx0; o.d1 = permute ? res->idx0 : res->idx1; o.v = res->val; o.nnz = res->nnz;
+		o.shape0 = res->shape0; o.shape1 = res->shape1; o.sort0 = permute ? 1 : 0;
+	}
 	if (permute) std::swap(res->idx0, res->idx1);                             // PermuteAccum {1,0}: same tuples, indices swapped
 	SPS_HIP(hipEventRecord(c->ev[7], st));
 	SPS_HIP(hipEventSynchronize(c->ev[7]));
@@ -280,12 +287,34 @@ extern "C" int spsamd_operand_prepare(spsamd_ctx *c, const spsamd_coo *X, char t
 		p.ctx = c; p.owns = true; p.lead = lead;
 		p.m = m;
 		const size_t n = m.nnz;
+		// All of the handle's memory is taken NOW, in one piece: tuples, packed tuples, row list, row pointer -- and, for a right
+		// operand with long rows, the column-window indices the first product with a heavy row will build.  (Measured on cfg2:
+		// taken later and separately, after the context's workspace exists, the same arrays make the kernels that gather from
+		// them at random -- the hash cells of the long rows -- 2.3x slower; presumably the fragments the driver then finds are
+		// smaller.)  Not for operands whose indices would be out of proportion: a stencil matrix has no heavy rows and
+		// millions of columns.
+		size_t want = (n + 64) * (16 + 12 + 8) + (m.nrow + 66) * 4 + 65536;
+		uint32_t maxlen = 0;
+		if (n) {
+			Prepared view;                                              // (the consolidated tuples still sit in the workspace)
+			view.ctx = c; view.m = m;
+			prepared_row_structure(c, &view);
+			maxlen = view.maxlen;
+		}
+		if ((role & SPSAMD_AS_B) && maxlen > 64) {
+			const uint64_t W = m.ncol > (uint64_t(1) << 21) ? 16384 : 8192, nwin = (m.ncol + W - 1) / W, nwp = (nwin + 7) & ~7ull, nrowb = m.nrow + 1;
+			const uint64_t idx = nrowb * (nwin + 1) * 4 + nrowb * nwp * 2 + (nrowb * nwin + 1) * 4 + (n + 8) * 12 + 8192;
+			size_t freeb = 0, totalb = 0;
+			if (idx <= 64 * (uint64_t)n * 16 && hipMemGetInfo(&freeb, &totalb) == hipSuccess && idx + want < freeb / 2) want += idx;
+		}
+		p.reserve(want);
 		p.m.row = p.get<int32_t>(n ? n : 1); p.m.col = p.get<int32_t>(n ? n : 1); p.m.val = p.get<double>(n ? n : 1);
 		if (n) {
 			SPS_HIP(hipMemcpyAsync(p.m.row, m.row, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
 			SPS_HIP(hipMemcpyAsync(p.m.col, m.col, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
 			SPS_HIP(hipMemcpyAsync(p.m.val, m.val, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 		}
+		prepared_row_structure(c, &p);                                  // the row pointer and the longest row (every product asks for them)
 		SPS_HIP(hipStreamSynchronize(c->stream));
 		guard.h = nullptr;
 		*out = h;
@@ -423,6 +452,7 @@ extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, i
 		const spsamd_coo *ops[1] = {A};
 		pick_output_set(c, ops, 1);
 		OutSet &o = c->out[c->cur_out];
+		c->own[c->cur_out].sort0 = -1;
 		o.i.ensure(n * 4 + 4); o.j.ensure(n * 4 + 4); o.v.ensure(n * 8 + 8);
 		// m.row is the leading (sorted) dimension: put dimensions back in place
 		int32_t *d0 = (int32_t *)o.i.p, *d1 = (int32_t *)o.j.p;
@@ -432,6 +462,7 @@ extern "C" int spsamd_consolidate(spsamd_ctx *c, const spsamd_coo *A, int so0, i
 		SPS_HIP(hipStreamSynchronize(c->stream));
 		res->nnz = n; res->nnz_a = n;
 		res->idx0 = d0; res->idx1 = d1; res->val = (double *)o.v.p;
+		{ auto &w = c->own[c->cur_out]; w.d0 = d0; w.d1 = d1; w.v = res->val; w.nnz = n; w.shape0 = A->shape0; w.shape1 = A->shape1; w.sort0 = so0; }
 		return SPSAMD_OK;
 	)
 }

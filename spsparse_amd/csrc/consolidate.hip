@@ -202,7 +202,11 @@ void consolidate_operand(spsamd_ctx *c, const spsamd_coo *X, int lead, int ref_l
 	if (shape[0] > (uint64_t(1) << 31) || shape[1] > (uint64_t(1) << 31))
 		throw Error{SPSAMD_EINVAL, "shape exceeds the int32 index range"};
 
-	if (X->mem == SPSAMD_MEM_DEVICE_VERIFIED && X->sort0 == lead) {       // the distributed step's own block / panel
+	bool own_result = false;                                            // a result of this context, chained back in as it stands
+	if (X->mem == SPSAMD_MEM_DEVICE && X->sort0 == lead)
+		for (const auto &o : c->own)
+			if (o.sort0 == X->sort0 && o.d0 == X->idx0 && o.d1 == X->idx1 && o.v == X->val && o.nnz == n && o.shape0 == X->shape0 && o.shape1 == X->shape1) own_result = true;
+	if ((X->mem == SPSAMD_MEM_DEVICE_VERIFIED || own_result) && X->sort0 == lead) {       // the distributed step's own block / panel
 		out->row = const_cast<int32_t *>(lead == 0 ? X->idx0 : X->idx1);
 		out->col = const_cast<int32_t *>(lead == 0 ? X->idx1 : X->idx0);
 		out->val = const_cast<double *>(X->val);

@@ -103,6 +103,9 @@ struct spsamd_ctx {
 	spsamd::Arena arena;
 	spsamd::OutSet out[2];                   // SINK_COO results (see OutSet)
 	int cur_out = 0;
+	// what each output set holds right now, where this library wrote it and knows it to be consolidated by `sort0` with
+	// valid indices: handed back as an operand (T = R*A, then C = T*R^T) it is taken as it is, without the inspection pass
+	struct OwnResult { const int32_t *d0 = nullptr, *d1 = nullptr; const double *v = nullptr; uint64_t nnz = 0, shape0 = 0, shape1 = 0; int sort0 = -1; } own[2];
 	spsamd::DevBuf rowstat_n, rowstat_s, rowstat_h;     // DIGEST row statistics
 	void *pinned = nullptr;                  // host staging for small readbacks / fetch
 	size_t pinned_cap = 0;
@@ -224,9 +227,12 @@ struct Prepared {
 	spsamd_ctx *ctx = nullptr;
 	ConMat m;                         // op(X), consolidated, row-major
 	int lead = 0;                     // the stored dimension that is m.row
-	bool owns = false;                // handle: the pieces are hipMalloc'ed and live until release()
-	std::vector<void *> owned;
-	uint64_t owned_bytes = 0;
+	bool owns = false;                // handle: the pieces live in device memory of the handle's own until release()
+	std::vector<void *> owned;        // its slabs (few and large: a handle's arrays are gathered from at random like the workspace's,
+	uint64_t owned_bytes = 0;         // and many small allocations cost the numeric kernels 5 % in address translation)
+	char *slab = nullptr;             // the slab being carved
+	size_t slab_left = 0;
+	void reserve(size_t bytes);       // make the next `bytes` of alloc() calls come out of one slab
 	// both roles
 	uint32_t *rowptr = nullptr;       // dense row pointer over nrow + 1 rows (the last one an empty sentinel): nrow + 2 entries
 	uint32_t maxlen = 0;              // longest row
@@ -269,6 +275,7 @@ struct MultiplyArgs {
 	                                         // event before the first kernel that reads them; its row pointer (pb->rowptr) is valid at once
 };
 void spgemm(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *res);
+void prepared_row_structure(spsamd_ctx *c, Prepared *p);      // its dense row pointer and longest row, now (spgemm.hip)
 
 // Shared body of the MM and MV entry points (capi.hip); `arena_ready`: the caller has reset the workspace
 // and may hold operands in it (the distributed step does); `parts`: records of derived structures the caller already

@@ -97,10 +97,10 @@ void DevBuf::release()
 	p = nullptr; cap = 0;
 }
 
-void *Prepared::alloc(size_t bytes)
+void Prepared::reserve(size_t bytes)
 {
-	if (!owns) return ctx->arena.alloc(bytes);
-	bytes = round_up(bytes ? bytes : 1, 256);
+	if (!owns || bytes <= slab_left) return;
+	bytes = round_up(bytes, size_t(2) << 20);
 	void *p = nullptr;
 	hipError_t e = hipMalloc(&p, bytes);
 	if (e != hipSuccess) {
@@ -109,6 +109,16 @@ void *Prepared::alloc(size_t bytes)
 	}
 	owned.push_back(p);
 	owned_bytes += bytes;
+	slab = (char *)p; slab_left = bytes;
+}
+
+void *Prepared::alloc(size_t bytes)
+{
+	if (!owns) return ctx->arena.alloc(bytes);
+	bytes = round_up(bytes ? bytes : 1, 256);
+	if (bytes > slab_left) reserve(bytes);
+	void *p = slab;
+	slab += bytes; slab_left -= bytes;
 	return p;
 }
 
@@ -117,6 +127,7 @@ void Prepared::release()
 	for (void *p : owned) (void)hipFree(p);
 	owned.clear();
 	owned_bytes = 0;
+	slab = nullptr; slab_left = 0;
 }
 
 } // namespace spsamd

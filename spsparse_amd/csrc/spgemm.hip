@@ -426,6 +426,12 @@ static void ensure_maxlen(spsamd_ctx *c, Prepared *pa, Prepared *pb)
 	if (n > 1) { need[1]->maxlen = hm.b; need[1]->have_maxlen = true; }
 }
 
+void prepared_row_structure(spsamd_ctx *c, Prepared *p)
+{
+	ensure_rowptr(c, p);
+	ensure_maxlen(c, p, p);
+}
+
 static const RowList &ensure_rowlist(spsamd_ctx *c, Prepared *p)
 {
 	if (p->have_rl) return p->rl;
@@ -708,6 +714,7 @@ static void spgemm_column_blocks(spsamd_ctx *c, MultiplyArgs &a, spsamd_result *
 	const bool coo = a.sink_kind == SPSAMD_SINK_COO;
 	const uint32_t nblk = (uint32_t)((B.ncol + colblk - 1) / colblk);
 	wait_b_tuples(c, a);
+	c->own[c->cur_out].sort0 = -1;                                  // (the blocks go through that output set, whatever the sink)
 	struct BlockOut { int32_t *i = nullptr, *j = nullptr; double *v = nullptr; uint64_t n = 0; };
 	struct Blocks {                                                 // the blocks' COO outputs until they are interleaved
 		std::vector<BlockOut> b;

@@ -508,6 +508,7 @@ void heavy_prepare(spsamd_ctx *c, Heavy &hv, const Bins &bins, const RowMeta &m,
 	hv.winprod = c->arena.get<uint32_t>((uint64_t)hv.n * hv.nwin);
 	const uint32_t nwp = (hv.nwin + 7u) & ~7u;
 	if (!have_index) {
+		pb->reserve(nrowb * hv.nwin1 * 4 + nrowb * nwp * 2 + (nrowb * hv.nwin + 1) * 4 + ((size_t)B.nnz + DENSE_R) * sizeof(BTup) + 4096);   // (a handle: one slab for all four)
 		pb->bwin = pb->get<uint32_t>(nrowb * hv.nwin1);
 		pb->wcnt = pb->get<uint16_t>(nrowb * nwp);
 		pb->W = hv.W; pb->nwin = hv.nwin; pb->nwp = nwp; pb->nrowb = nrowb;
