@@ -42,7 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
 
 
 def parse():

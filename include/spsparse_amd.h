@@ -28,8 +28,8 @@
  *     columns (16384 above 2^21 columns), at most 2048 of them.  A product with a heavy row and more than
  *     2^25 columns in op(B) is multiplied by column blocks of op(B), 2^25 columns at a time (same result,
  *     slower: every block repeats the work on A and a COO result is assembled by one more pass).
- *   - the heavy-row path keeps dense indices of rows(op(B)) x windows entries in the workspace (12 bytes per
- *     row and window: 1.6 GB for a 2^20-square matrix, 50 GB at 2^23).  Where they would not fit the device the
+ *   - the heavy-row path keeps dense indices of rows(op(B)) x windows entries in the workspace (10 bytes per
+ *     row and window: 1.4 GB for a 2^20-square matrix, 43 GB at 2^23).  Where they would not fit the device the
  *     product also goes by column blocks, narrow enough for them to fit; SPSAMD_ENOMEM only if one window's
  *     share does not.
  */

@@ -969,6 +969,16 @@ def test_presorted_operands(ctx):
     want = orc.multiply(A, B)
     _check(_dev(ctx, As, Bs), want)
     _check(_dev(ctx, A, B), want)
+    # a sort_order that is CLAIMED but not there (set_sorted() on unsorted tuples): the reference would quietly mis-compute;
+    # here the dense row pointer is built from the tuples' side and would be left with entries nobody wrote -- rejected
+    # (ADVICE r2).  Rows ascending but columns not, or duplicates, stay "trusted" like Consolidate<> trusts them.
+    from spsparse_amd import capi
+    lie = orc.Mat(a0[::-1].copy(), a1[::-1].copy(), av[::-1].copy(), (30, 30), sort0=0)
+    with pytest.raises(capi.SpsamdError) as e:
+        _dev(ctx, lie, Bs)
+    assert e.value.code == -2 and "sort_order" in e.value.msg
+    with pytest.raises(capi.SpsamdError):
+        _dev(ctx, As, orc.Mat(b0[::-1].copy(), b1[::-1].copy(), bv[::-1].copy(), (30, 30), sort0=0))
 
 
 @pytest.mark.parametrize("dups,zeros", [(True, True), (False, True), (False, False)])
