@@ -182,6 +182,7 @@ const char *spsamd_version(void);
  *   no_tiles, no_wmajor, xcd          1: no tiles | no window-major copy of B | XCD-partitioned cell lists
  *   emit_path       1 | 2             COO order of a hash cell: LDS radix sort | bitonic network (default: by cell width)
  *   light_path      1                 binned light kernels even where every row is light
+ *   light_two_pass  1                 all-light COO sink: count, scan, store (two compute passes) instead of one pass + gather
  *   trace           1                 the symbolic phase prints its choices (tile scheme, cell counts) to stderr
  *   index_budget_mb > 0               cap of the heavy rows' window indices (default: 80 % of the free device memory);
  *                                     beyond it the product goes by column blocks of op(B)

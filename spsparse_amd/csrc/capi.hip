@@ -48,8 +48,8 @@ extern "C" int spsamd_ctx_create(spsamd_ctx **out, int device, void *hip_stream)
 	if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
 	for (auto &e : c->ev_side2) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { spsamd_ctx_destroy(c); return SPSAMD_EHIP; }
 	// developer knobs: the environment is consulted here and nowhere else
-	static const char *const knobs[] = {"window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path", "no_wmajor", "direct_min", "tiles_v1", "long_cap", "long_dense_min", "index_budget_mb", "trace"};
-	static const char *const envs[] = {"SPSAMD_W", "SPSAMD_CELL_CAP", "SPSAMD_DENSE_MIN", "SPSAMD_NO_TILES", "SPSAMD_XCD", "SPSAMD_EMIT_PATH", "SPSAMD_LIGHT_PATH", "SPSAMD_NO_WMAJOR", "SPSAMD_DIRECT_MIN", "SPSAMD_TILES_V1", "SPSAMD_LONG_CAP", "SPSAMD_LONG_DENSE_MIN", "SPSAMD_INDEX_BUDGET_MB", "SPSAMD_TRACE"};
+	static const char *const knobs[] = {"window", "cell_cap", "dense_min", "no_tiles", "xcd", "emit_path", "light_path", "no_wmajor", "direct_min", "tiles_v1", "long_cap", "long_dense_min", "index_budget_mb", "trace", "light_two_pass"};
+	static const char *const envs[] = {"SPSAMD_W", "SPSAMD_CELL_CAP", "SPSAMD_DENSE_MIN", "SPSAMD_NO_TILES", "SPSAMD_XCD", "SPSAMD_EMIT_PATH", "SPSAMD_LIGHT_PATH", "SPSAMD_NO_WMAJOR", "SPSAMD_DIRECT_MIN", "SPSAMD_TILES_V1", "SPSAMD_LONG_CAP", "SPSAMD_LONG_DENSE_MIN", "SPSAMD_INDEX_BUDGET_MB", "SPSAMD_TRACE", "SPSAMD_LIGHT_TWO_PASS"};
 	static_assert(sizeof knobs / sizeof knobs[0] == sizeof envs / sizeof envs[0], "one environment variable per knob");
 	for (size_t k = 0; k < sizeof knobs / sizeof knobs[0]; ++k)
 		if (const char *e = getenv(envs[k])) (void)spsamd_ctx_set_tuning(c, knobs[k], atol(e));
@@ -66,7 +66,7 @@ extern "C" int spsamd_ctx_set_tuning(spsamd_ctx *c, const char *name, long value
 	struct { const char *n; int *p; } tab[] = {
 		{"window", &c->tune.window}, {"cell_cap", &c->tune.cell_cap}, {"dense_min", &c->tune.dense_min},
 		{"no_tiles", &c->tune.no_tiles}, {"xcd", &c->tune.xcd}, {"emit_path", &c->tune.emit_path},
-		{"light_path", &c->tune.light_path}, {"no_wmajor", &c->tune.no_wmajor}, {"direct_min", &c->tune.direct_min}, {"tiles_v1", &c->tune.tiles_v1}, {"long_cap", &c->tune.long_cap}, {"long_dense_min", &c->tune.long_dense_min}, {"index_budget_mb", &c->tune.index_budget_mb}, {"trace", &c->tune.trace},
+		{"light_path", &c->tune.light_path}, {"no_wmajor", &c->tune.no_wmajor}, {"direct_min", &c->tune.direct_min}, {"tiles_v1", &c->tune.tiles_v1}, {"long_cap", &c->tune.long_cap}, {"long_dense_min", &c->tune.long_dense_min}, {"index_budget_mb", &c->tune.index_budget_mb}, {"trace", &c->tune.trace}, {"light_two_pass", &c->tune.light_two_pass},
 	};
 	for (auto &t : tab) if (!std::strcmp(t.n, name)) { *t.p = (int)value; return SPSAMD_OK; }
 	c->last_error = std::string("unknown tuning knob: ") + name;

@@ -82,6 +82,7 @@ struct Tuning {
 	int xcd = 0;
 	int emit_path = 0;           // 0 auto | 1 no bitmap rank | 2 bitonic only
 	int light_path = 0;          // 0 auto | 1 generic k_light only
+	int light_two_pass = 0;      // 1: the all-light COO sink counts, scans and stores (two compute passes) instead of one pass + gather
 	int no_wmajor = 0;           // 1: dense cells read the row-major B through bwin (no window-major copy)
 	int tiles_v1 = 0;            // tile kernel of the hash-class cells: 0 auto, 1 first generation, 2 hash tiles v2, 3 bitmap rank
 	int long_cap = 0;            // 0: cell_cap; grouping target of the hash cells of rows too long for tiles (<= 4096)

@@ -282,13 +282,25 @@ __global__ __launch_bounds__(256, 8) void k_light_direct(uint32_t nrow, const ui
 		if (MODE == MODE_COUNT) {
 			if (has_row && s == 0) sk.segcount[r] = (uint32_t)__popcll(gmask);
 		} else if (MODE == MODE_STORE) {
-			if (has_row) {
+			if (sk.segoff) {                                             // offsets known: the second of two passes
+				if (has_row) {
+					if (out) {
+						const uint32_t rk = (uint32_t)__popcll(gmask & ((1ull << s) - 1ull));
+						const int64_t o = sk.segoff[r] + rk;
+						sk.out_i[o] = rowid; sk.out_j[o] = (int32_t)mycol; sk.out_v[o] = value;
+					}
+					if (s == 0) sk.segactual[r] = (uint32_t)__popcll(gmask);
+				}
+			} else {
+				// none yet (one compute pass: spgemm_all_light): the tuples of this wave's G rows go, packed in row order, to the
+				// wave round's own 64 slots of a sparse buffer -- round q holds rows q G .. q G + G - 1, so the rounds' runs in
+				// order ARE the row-major result -- and are gathered once every round's count is known
+				const uint32_t q = vb * 4u + w;
 				if (out) {
-					const uint32_t rk = (uint32_t)__popcll(gmask & ((1ull << s) - 1ull));
-					const int64_t o = sk.segoff[r] + rk;
+					const int64_t o = (int64_t)q * 64 + (int64_t)__popcll(bal & lanemask_lt());
 					sk.out_i[o] = rowid; sk.out_j[o] = (int32_t)mycol; sk.out_v[o] = value;
 				}
-				if (s == 0) sk.segactual[r] = (uint32_t)__popcll(gmask);
+				if (lane == 0) sk.segactual[q] = (uint32_t)__popcll(bal);
 			}
 		} else {
 			if (sk.row_nnz) {
@@ -330,6 +342,30 @@ static void launch_light_direct(spsamd_ctx *c, uint32_t nrow, const uint32_t *ap
 	const unsigned grid = std::min<unsigned>((nrow + per - 1) / per, (unsigned)c->num_cu * 8u * 4u);
 	if (k64) k_light_direct<S, MODE, true><<<dim3(grid), dim3(256), 0, c->stream>>>(nrow, aptr, acol, aval, bptr, B.col, B.val, ep, sk, pc);
 	else k_light_direct<S, MODE, false><<<dim3(grid), dim3(256), 0, c->stream>>>(nrow, aptr, acol, aval, bptr, B.col, B.val, ep, sk, pc);
+	SPS_LAUNCH_CHECK();
+}
+
+// The wave rounds' tuples from their 64-slot places in the sparse buffer to their final, packed places: thread = (round, slot).
+__global__ __launch_bounds__(256) void k_light_gather(uint32_t nrow, uint32_t logs, const uint32_t *cnt, const int64_t *off,
+	const int32_t *si, const int32_t *sj, const double *sv, int32_t *oi, int32_t *oj, double *ov)
+{
+	const uint64_t total = (uint64_t)nrow << logs, stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+		const uint32_t r = (uint32_t)(t >> logs), s = (uint32_t)t & ((1u << logs) - 1u);
+		if (s < cnt[r]) {
+			const int64_t o = off[r] + s;
+			oi[o] = si[t]; oj[o] = sj[t]; ov[o] = sv[t];
+		}
+	}
+}
+
+void launch_light_gather(spsamd_ctx *c, uint32_t nrow, uint32_t S, const uint32_t *cnt, const int64_t *off,
+	const int32_t *si, const int32_t *sj, const double *sv, int32_t *oi, int32_t *oj, double *ov)
+{
+	const uint32_t logs = S == 8 ? 3 : (S == 16 ? 4 : (S == 32 ? 5 : 6));
+	const uint64_t total = (uint64_t)nrow << logs;
+	const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, (uint64_t)c->num_cu * 64u);
+	k_light_gather<<<dim3(grid ? grid : 1), dim3(256), 0, c->stream>>>(nrow, logs, cnt, off, si, sj, sv, oi, oj, ov);
 	SPS_LAUNCH_CHECK();
 }
 

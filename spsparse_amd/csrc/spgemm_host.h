@@ -68,6 +68,8 @@ static inline float elapsed(hipEvent_t a, hipEvent_t b)
 template <int MODE> void launch_light(spsamd_ctx *c, const Bins &b, const RowMeta &m, const EmitParams &ep, const SinkParams &sk);             // k_light.hip
 template <int MODE> void launch_light_direct_s(spsamd_ctx *c, uint32_t maxp, uint32_t nrow, const uint32_t *aptr, const int32_t *acol, const double *aval,
 	const uint32_t *bptr, const ConMat &B, bool k64, const EmitParams &ep, const SinkParams &sk, unsigned long long *pc);                         // k_light.hip
+void launch_light_gather(spsamd_ctx *c, uint32_t nrow, uint32_t S, const uint32_t *cnt, const int64_t *off,
+	const int32_t *si, const int32_t *sj, const double *sv, int32_t *oi, int32_t *oj, double *ov);                                                    // k_light.hip
 template <int MODE> void launch_mid(spsamd_ctx *c, const Bins &b, const MidCells &mc, const RowMeta &m, const EmitParams &ep, const SinkParams &sk);  // k_hash.hip
 template <int MODE> void launch_hash_windowed(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk);  // k_hash.hip
 template <int MODE> void launch_tiles_v1(spsamd_ctx *c, const Heavy &hv, const RowMeta &m, const EmitParams &ep, const SinkParams &sk);       // k_hash.hip

@@ -894,6 +894,49 @@ def test_poisson_exact(ctx):
     assert set(np.unique(got[2]).tolist()) <= {-8., 1., 2., 18., 19., 20.}
 
 
+@pytest.mark.parametrize("two_pass", [0, 1], ids=["one_pass_and_gather", "count_scan_store"])
+def test_all_light_coo_sink_both_ways(ctx, two_pass):
+    """The COO sink of a product in which every row is light: one compute pass into per-row slots plus a gather (default), or
+    count / scan / store (the `light_two_pass` knob; also what a product too large for the sparse buffer takes).  Random
+    values with cancellations and explicit zeros, scale vectors, 'T', empty rows, rows of every slot class (S = 8 .. 64)."""
+    rng = np.random.default_rng(41)
+    ctx.set_tuning("light_two_pass", two_pass)
+    try:
+        for trial in range(24):
+            n = int(rng.integers(3, 400))
+            per = [1, 2, 3, 5, 7][trial % 5]                       # tuples per row of either operand: products per row up to per^2 <= 49
+            def band(m, k, per_):
+                rows = np.repeat(np.arange(m), per_)
+                cols = rng.integers(0, k, rows.size)
+                vals = rng.integers(-2, 3, rows.size).astype(np.float64)      # small integers: exact sums, real cancellations, zeros
+                keep = rng.uniform(size=rows.size) < 0.85                     # some rows shorter, some empty
+                return orc.Mat(rows[keep], cols[keep], vals[keep], (m, k))
+            tA, tB = ".T"[trial % 2], ".T"[(trial // 2) % 2]
+            m, k, nn = n, int(rng.integers(3, 400)), int(rng.integers(3, 400))
+            A = band(k, m, per) if tA == "T" else band(m, k, per)
+            B = band(nn, k, per) if tB == "T" else band(k, nn, per)
+            if tA == "T" or tB == "T":
+                # a transposed band has no bound on its row lengths: only keep the case if it is still all-light, else it simply takes the binned path
+                pass
+            si = _rand_vec(rng, m) if trial % 3 == 0 else None
+            sk = _rand_vec(rng, nn) if trial % 4 == 1 else None
+            want = orc.multiply(A, B, 2.0, si, tA, None, tB, sk, rowwise=True)
+            got = _dev(ctx, A, B, C_=2.0, scalei=si, tA=tA, tB=tB, scalek=sk)
+            _check(got, want, exact=True)
+        # cfg3 / cfg5 shapes
+        N = 48
+        a = wl.poisson2d(N)
+        A = orc.Mat(*a, sort0=0)
+        _check(_dev(ctx, A, A), orc.multiply(A, A, rowwise=True), exact=True)
+        R3, A3 = orc.Mat(*wl.aggregation3d(12), sort0=0), orc.Mat(*wl.laplace3d(12), sort0=0)
+        wt = orc.multiply(R3, A3, rowwise=True)
+        gt = _dev(ctx, R3, A3)
+        _check(gt, wt, exact=True)
+        assert gt[3].rows_light == R3.shape[0] and gt[3].rows_heavy == 0     # the all-light direct kernel took it
+    finally:
+        ctx.set_tuning("light_two_pass", 0)
+
+
 def test_galerkin_exact(ctx):
     """cfg5 at N=16: T = R*A, C = T*R^T ('T' flag, multiply_sparse.hpp:168); closed forms
     nnz(T)=32nc^3-24nc^2, nnz(C)=7nc^3-6nc^2, C values in {24,-4}."""
