@@ -1,8 +1,7 @@
-"""Multi-GPU SpGEMM, the harness side: row-block boundaries (cost model, measured rebalancing) and test
-transports.  The STEP itself -- consolidate the own block, exchange the needed B row panels, multiply --
-is spsamd_dist_multiply behind the C ABI (csrc/dist.hip, grouped ncclSend / ncclRecv over RCCL);
-exchange_b_panels below is the same exchange in torch tensors, kept as the CPU model the gloo tests
-check the partition logic with.  No reduction anywhere: C stays row partitioned.
+"""Multi-GPU SpGEMM, the harness side: row-block boundaries (cost model, measured rebalancing), the reduction of the
+ranks' digests and a test transport.  The STEP itself -- consolidate the own block, exchange the needed B row panels,
+multiply -- is spsamd_dist_multiply behind the C ABI (csrc/dist.hip, grouped ncclSend / ncclRecv over RCCL).  No
+reduction of C anywhere: it stays row partitioned.
 
 The reference is single threaded and has no counterpart of this module
 (SURVEY.md section 8e).  Output row i of C depends only on row i of op(A) and
@@ -98,64 +97,6 @@ def row_products(a_row, a_col, b_rowlen, n_rows):
     out = torch.zeros(n_rows, dtype=torch.int64, device=a_row.device)
     out.index_add_(0, a_row.long(), b_rowlen[a_col.long()].to(torch.int64))
     return out
-
-
-def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None, whole_block_fraction=0.5):
-    """All-to-allv of the B row panels this rank's A block needs.
-
-    a_col           inner indices k of this rank's A block tuples
-    b_row/col/val   this rank's own block of B (rows bounds[rank]..bounds[rank+1]), row-major sorted
-    bounds          row-block boundaries of B over the inner dimension, len world+1
-    Returns (row, col, val) of the received panel: the tuples of every B row
-    this rank needs (plus, from owners it needs more than `whole_block_fraction`
-    of, their whole block), sorted row-major (owner blocks arrive in rank
-    order), and the number of tuples received from other ranks.
-    """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = b_row.device
-    sizes = [bounds[q + 1] - bounds[q] for q in range(world)]
-    my_lo, my_n = bounds[rank], sizes[rank]
-
-    # 1. which rows of each owner do I need?  one byte per row of the inner dimension
-    need = torch.zeros(n_inner, dtype=torch.uint8, device=dev)
-    need[a_col.long()] = 1
-    their_need = torch.empty(my_n * world, dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(their_need, need, output_split_sizes=[my_n] * world, input_split_sizes=sizes, group=group)
-
-    # 2. pack, per requester, the tuples of my rows it asked for.  A requester that needs most of
-    #    my rows (R-MAT blocks need 80-98 % of B) gets the whole block: no per-tuple selection, and
-    #    rows it did not ask for are simply never referenced by its A block.
-    local_row = (b_row.long() - my_lo)
-    masks = their_need.view(world, my_n) if my_n else their_need.view(world, 0)
-    frac = (masks.sum(dim=1).to(torch.float64) / max(my_n, 1)).tolist()
-    sel = []
-    for p in range(world):
-        if frac[p] >= whole_block_fraction:
-            sel.append(None)
-        else:
-            sel.append(torch.nonzero(masks[p][local_row], as_tuple=False).flatten())
-    counts = [b_row.numel() if s_ is None else s_.numel() for s_ in sel]
-    send_counts = torch.tensor(counts, dtype=torch.int64, device=dev)
-    recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-
-    def pack(x):
-        return torch.cat([x if s_ is None else x[s_] for s_ in sel]) if world > 1 else (x if sel[0] is None else x[sel[0]])
-    s_row, s_col, s_val = pack(b_row), pack(b_col), pack(b_val)
-    in_splits = counts
-    out_splits = [int(x) for x in recv_counts.tolist()]
-    total = sum(out_splits)
-
-    # 3. the all-to-allv proper: (row, col, val) panels
-    r_row = torch.empty(total, dtype=b_row.dtype, device=dev)
-    r_col = torch.empty(total, dtype=b_col.dtype, device=dev)
-    r_val = torch.empty(total, dtype=b_val.dtype, device=dev)
-    dist.all_to_all_single(r_row, s_row, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-    dist.all_to_all_single(r_col, s_col, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-    dist.all_to_all_single(r_val, s_val, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-    remote = total - out_splits[rank]
-    return r_row, r_col, r_val, remote
 
 
 def reduce_digest(count, digest_sum, digest_hash, device, group=None):

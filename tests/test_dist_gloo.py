@@ -1,10 +1,10 @@
 """The multi-GPU path's host logic on CPU: world_size 2 over gloo.
 
-Row-block partition + the all-to-allv of needed B row panels
-(spsparse_amd/dist.py); each rank's block product is computed by the ORACLE
-here (no GPU in this container) and the concatenation must equal the oracle's
-product of the whole matrices -- the property the sharding relies on:
-C's rows are independent (multiply_sparse.hpp:192), no reduction.
+Row-block partition (spsparse_amd/dist.py: cost-balanced bounds, digest reduction) + a torch model of the all-to-allv of
+needed B row panels (exchange_b_panels below: what csrc/dist.hip does on the device, restated here because no GPU is in
+this container -- the C code itself is driven by two real ranks in tests/dist_worker.py on the GPU box); each rank's
+block product is computed by the ORACLE and the concatenation must equal the oracle's product of the whole matrices --
+the property the sharding relies on: C's rows are independent (multiply_sparse.hpp:192), no reduction.
 """
 import os
 import socket
@@ -18,6 +18,65 @@ import torch.multiprocessing as mp
 from oracle import binding as orc
 from spsparse_amd import dist as sd
 from spsparse_amd import workloads as wl
+
+
+def exchange_b_panels(a_col, b_row, b_col, b_val, bounds, n_inner, group=None, whole_block_fraction=0.5):
+    """All-to-allv of the B row panels this rank's A block needs.
+
+    a_col           inner indices k of this rank's A block tuples
+    b_row/col/val   this rank's own block of B (rows bounds[rank]..bounds[rank+1]), row-major sorted
+    bounds          row-block boundaries of B over the inner dimension, len world+1
+    Returns (row, col, val) of the received panel: the tuples of every B row
+    this rank needs (plus, from owners it needs more than `whole_block_fraction`
+    of, their whole block), sorted row-major (owner blocks arrive in rank
+    order), and the number of tuples received from other ranks.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = b_row.device
+    sizes = [bounds[q + 1] - bounds[q] for q in range(world)]
+    my_lo, my_n = bounds[rank], sizes[rank]
+
+    # 1. which rows of each owner do I need?  one byte per row of the inner dimension
+    need = torch.zeros(n_inner, dtype=torch.uint8, device=dev)
+    need[a_col.long()] = 1
+    their_need = torch.empty(my_n * world, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(their_need, need, output_split_sizes=[my_n] * world, input_split_sizes=sizes, group=group)
+
+    # 2. pack, per requester, the tuples of my rows it asked for.  A requester that needs most of
+    #    my rows (R-MAT blocks need 80-98 % of B) gets the whole block: no per-tuple selection, and
+    #    rows it did not ask for are simply never referenced by its A block.
+    local_row = (b_row.long() - my_lo)
+    masks = their_need.view(world, my_n) if my_n else their_need.view(world, 0)
+    frac = (masks.sum(dim=1).to(torch.float64) / max(my_n, 1)).tolist()
+    sel = []
+    for p in range(world):
+        if frac[p] >= whole_block_fraction:
+            sel.append(None)
+        else:
+            sel.append(torch.nonzero(masks[p][local_row], as_tuple=False).flatten())
+    counts = [b_row.numel() if s_ is None else s_.numel() for s_ in sel]
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=dev)
+    recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+
+    def pack(x):
+        return torch.cat([x if s_ is None else x[s_] for s_ in sel]) if world > 1 else (x if sel[0] is None else x[sel[0]])
+    s_row, s_col, s_val = pack(b_row), pack(b_col), pack(b_val)
+    in_splits = counts
+    out_splits = [int(x) for x in recv_counts.tolist()]
+    total = sum(out_splits)
+
+    # 3. the all-to-allv proper: (row, col, val) panels
+    r_row = torch.empty(total, dtype=b_row.dtype, device=dev)
+    r_col = torch.empty(total, dtype=b_col.dtype, device=dev)
+    r_val = torch.empty(total, dtype=b_val.dtype, device=dev)
+    dist.all_to_all_single(r_row, s_row, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    dist.all_to_all_single(r_col, s_col, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    dist.all_to_all_single(r_val, s_val, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    remote = total - out_splits[rank]
+    return r_row, r_col, r_val, remote
+
 
 
 def _free_port():
@@ -55,7 +114,7 @@ def _worker(rank, world, port, kind, out_dir):
         ma = (a0 >= a_bounds[rank]) & (a0 < a_bounds[rank + 1])
         mb = (b0 >= b_bounds[rank]) & (b0 < b_bounds[rank + 1])
         # exact panels (whole_block_fraction > 1): exactly the B rows this block needs, row-major sorted
-        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner,
+        r_row, r_col, r_val, remote = exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner,
                                                            whole_block_fraction=2.0)
         needed = np.unique(a1[ma])
         want_mask = np.isin(b0, needed)
@@ -63,7 +122,7 @@ def _worker(rank, world, port, kind, out_dir):
         assert np.array_equal(r_col.numpy(), b1[want_mask]) and np.array_equal(r_val.numpy(), bv[want_mask])
         assert remote == int(np.sum(want_mask & ~mb))
         # default: owners this block needs most of send their whole block -- a sorted superset
-        r_row, r_col, r_val, remote = sd.exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner)
+        r_row, r_col, r_val, remote = exchange_b_panels(t(a1[ma]), t(b0[mb]), t(b1[mb]), t(bv[mb]), b_bounds, n_inner)
         got_rows = r_row.numpy().astype(np.int64)
         assert np.all(np.diff(got_rows) >= 0)
         ncolb = b[3][1]
