@@ -390,6 +390,7 @@ void fetch_panel(spsamd_dist *d, const spsamd_coo *A_block, char transpose_A, co
 	const uint64_t my_lo = b_bounds[me];
 	const uint32_t my_n = (uint32_t)(b_bounds[me + 1] - my_lo);
 
+	d->broken = true;                                                // until the rounds are through (or an agreed error ends the step): a failure in between leaves the peers waiting
 	// ---- round buffers first: a rank that fails below still takes part in the rounds
 	uint8_t *need = c->arena.get<uint8_t>(n_inner + 1);
 	uint8_t *their = c->arena.get<uint8_t>((size_t)my_n * W + 1);   // [peer][own row]: does the peer need it
@@ -458,7 +459,6 @@ void fetch_panel(spsamd_dist *d, const spsamd_coo *A_block, char transpose_A, co
 		}
 		exchange(d, s, 3, false);
 	}
-	d->broken = true;                                                // from here to the end of round 2 a failure leaves the peers waiting
 
 	// ---- 2. what to send, where the panel's rows go: one read-back
 	uint32_t *mlen = c->arena.get<uint32_t>((size_t)my_n * W + 1);
@@ -491,7 +491,8 @@ void fetch_panel(spsamd_dist *d, const spsamd_coo *A_block, char transpose_A, co
 		d->broken = false;
 		if (local.code) throw local;
 		const uint32_t oobh = read_back(c, oob);
-		if (oobh) throw Error{SPSAMD_EINVAL, "B_block holds a tuple whose op(B) row lies outside this rank's b_bounds"};
+		if (oobh) throw Error{SPSAMD_EINVAL, B_block ? "B_block holds a tuple whose op(B) row lies outside this rank's b_bounds"
+			: "with B_block == NULL the A block is the B block: it holds a tuple whose row lies outside this rank's b_bounds"};
 		throw Error{SPSAMD_EPEER, "another rank of the communicator rejected its operands (status " + std::to_string(-(int)h[0]) + "): nothing was multiplied"};
 	}
 	const uint32_t *send_tuples = h.data() + 1, *recv_at = h.data() + 1 + W;
