@@ -19,6 +19,9 @@ namespace spsamd {
 // are read as one 12 R-byte piece, and the sums go to the LDS accumulator with ds_add_f64.
 // Occupancy: 16 waves per CU (two 512-thread workgroups, or one of 1024) = 4 per SIMD, so the kernel
 // is held to 128 VGPRs (launch bound 4): a build that needs more silently halves the occupancy.
+// The COUNT launch (first pass of the COO sink) needs no sums: its "accumulator" is one BYTE per column of the window (8 KB
+// instead of 64 KB, a scan-out of W / 16 16-byte words instead of W slots), set with plain byte stores -- every writer
+// stores the same 1 (29.0 -> 28.0 ms on cfg2; the launch is bound by the B reads, not by the accumulator).
 template <int W, int NT, int MODE, bool PAT>
 __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
 	const uint32_t *widx, uint64_t kstride, uint64_t wstride, uint32_t narrow, EmitParams ep, SinkParams sk)
@@ -30,7 +33,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	constexpr int R = DENSE_R;
 	constexpr int NWORD = W / 64;            // bitmap words of one batch (W items)
 	constexpr int WPL = NWORD / 64;          // words per lane of the per-wave copy
-	__shared__ double acc[W + 64];           // + one dump slot per lane: tuples past the end of a segment's last item land there
+	__shared__ double acc[MODE == MODE_COUNT ? 1 : W + 64];      // + one dump slot per lane: tuples past the end of a segment's last item land there
+	__shared__ __attribute__((aligned(16))) uint8_t ctouch[MODE == MODE_COUNT ? W : 16];     // COUNT: the touched columns
 	__shared__ uint32_t s_cpref[NT + 1];     // compacted segments: exclusive ITEM prefix (+ total)
 	__shared__ uint2 s_cse[NT];              // first tuple of the segment, one past its last
 	__shared__ double s_caval[NT];           // the A value
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	// EMPTY slot of a cell with products of both signs was re-evaluated from the operands: 4.8 s instead of 11 ms on a
 	// scale-18 R-MAT with random signs.)
 	const double CLEAN = (PAT && MODE != MODE_COUNT) ? -0.0 : 0.0;
-	for (int q = tid; q < W + 64; q += NT) acc[q] = CLEAN;
+	if (MODE == MODE_COUNT) { for (int q = tid; q < W / 16; q += NT) reinterpret_cast<uint4 *>(ctouch)[q] = make_uint4(0, 0, 0, 0); }
+	else for (int q = tid; q < W + 64; q += NT) acc[q] = CLEAN;
 	for (int q = tid; q < NWORD; q += NT) s_bmask[q] = 0ull;
 	const bool plain = ep.C == 1.0 && !ep.si_pos && !ep.sk_pos;    // uniform: the emitted value is the sum itself
 	const unsigned long long laneK = (unsigned long long)lane * 0x9E3779B97F4A7C15ull;
@@ -239,8 +244,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 					for (int u = 0; u < R; ++u) {
 						// a tuple past the segment's end goes to the lane's dump slot: straight-line code, no exec juggling
 						const uint32_t slot = (uint32_t)u < nv_ ? (ABL(ep, 64) ? (piece.w[3 * u] & (W - 1)) : piece.w[3 * u] - wbase) : (uint32_t)W + lane;
-						if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[slot] = av_; }          // no LDS accumulate
-						else if (MODE == MODE_COUNT) acc[slot] = 1.0;        // structural: touched
+						if (ABL(ep, 32)) { if (piece.w[3 * u + 2] == 0x7FF12345u) acc[MODE == MODE_COUNT ? 0 : slot] = av_; }          // no LDS accumulate
+						else if (MODE == MODE_COUNT) { if ((uint32_t)u < nv_) ctouch[slot] = (uint8_t)1; }      // structural: touched
 						else {
 							const double pv = av_ * __hiloint2double((int)piece.w[3 * u + 2], (int)piece.w[3 * u + 1]);
 							atomicAdd(&acc[slot], pv);
@@ -312,6 +317,29 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			(unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)X0);
 		double r_sum = 0;
 		unsigned long long r_hash = 0;
+		if constexpr (MODE == MODE_COUNT) {
+			// the touched columns of the window (those scalek allows): sixteen flag bytes per thread, cleaned on the way
+			static_assert(W / 16 == NT, "sixteen flag bytes per thread");
+			uint32_t cnt = 0;
+			{
+				uint4 *cw = reinterpret_cast<uint4 *>(ctouch);
+				const uint4 x = cw[tid];
+				const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+				if (x.x | x.y | x.z | x.w) {
+					cw[tid] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						if (!ep.sk_pos) cnt += (uint32_t)__popc(xs[q]);
+						else {
+#pragma unroll
+							for (int b = 0; b < 4; ++b)
+								if (((xs[q] >> (8 * b)) & 1u) && col_allowed(ep, (int32_t)(wbase + tid * 16u + (uint32_t)(4 * q + b)))) ++cnt;
+						}
+					}
+				}
+			}
+			wcount = (uint32_t)wave_reduce_sum((unsigned long long)cnt);
+		} else {
 #pragma unroll
 		for (int gi = 0; gi < GPW; ++gi) {
 			int grp = wv * GPW + gi;
@@ -322,8 +350,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 				const bool touched = __double_as_longlong(x) != (long long)0x8000000000000000ull;
 				x = pat_fix_wave(touched && !(fabs(x) > pthr), x, (int32_t)(wbase + grp * 64 + lane), m, pbeg, pend);
 			}
-			if (MODE == MODE_COUNT) ok = (x != 0) && col_allowed(ep, (int32_t)(wbase + grp * 64 + lane));
-			else if (plain) ok = x != 0;
+			if (plain) ok = x != 0;
 			else ok = emit_value(ep, a_scale, (int32_t)(wbase + grp * 64 + lane), x, &x);
 			v[gi] = x;
 			nzmask[gi] = __ballot(ok);
@@ -336,6 +363,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 				else r_sum += ok ? x : 0.0;
 				X0 += 64ull * MIXK;
 			}
+		}
 		}
 		if (MODE == MODE_DIGEST) {
 			if (lane == 0) d_cnt += wcount;
@@ -390,7 +418,7 @@ void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const
 	if (hv.wptr) { widx = hv.wptr; kstride = 1; wstride = hv.nrowb; m.btup = hv.btw; }
 	const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;    // 32-bit byte offsets into B suffice
 	if (hv.W == 8192) {
-		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);
+		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);      // (COUNT would fit four per CU: measured 28.0 / 31.2 / 33.2 ms at two / three / four -- the B reads' L2 share)
 		if (grid >= 64) grid &= ~7u;
 #ifdef SPSAMD_STAMPS
 		SinkParams sk2 = sk;

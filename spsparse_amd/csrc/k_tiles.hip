@@ -509,41 +509,71 @@ __global__ __launch_bounds__(BM_NT, 4) void k_bm_tiles(const Tile *tiles, uint32
 				if (tid == 0) sk.segcount[seg] = tot;
 			} else {
 				// COO: rank order IS column order.  Usually every column of the cell yields a tuple and its place is its
-				// rank; only where a sum cancelled to exactly 0 (or scalek drops a column) the survivors are compacted by scans
-				uint32_t nbad = 0;
-				for (uint32_t base = 0; base < distinct; base += NT) {      // (uniform trips)
-					const uint32_t i = base + tid;
-					const bool valid = i < distinct;
-					const uint32_t rel = valid ? colof[i] : 0u;
-					double v = valid ? acc[i] : 1.0;
-					if (PAT) {
-						const bool need = valid && !(fabs(v) > pthr);
-						v = pat_fix_wave(need, v, (int32_t)(colbase + rel), m, tile.beg, tile.end);
-						if (need) acc[i] = v;                               // (kept: the store loop below reads it)
-					}
-					const bool ok = !valid || (plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v));
-					if (!ok) ++nbad;
-				}
-				const int any_bad = __syncthreads_or((int)nbad);
+				// rank: the tuples are stored there at once.  Only where a sum cancelled to exactly 0 (or scalek drops a
+				// column) the dropped ones are marked (column -1) and the survivors moved down afterwards, every thread
+				// re-reading what it stored itself
 				const int64_t o = sk.segoff[seg];
-				uint32_t run = 0;
-				for (uint32_t ibase = 0; ibase < distinct; ibase += NT) {
-					const uint32_t i = ibase + tid;
-					bool ok = false; double v = 0; uint32_t rel = 0;
-					if (i < distinct) {
-						rel = colof[i];
-						v = acc[i];
-						acc[i] = 0.0;
-						ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v);
+				uint32_t nbad = 0, run = 0;
+				int any_bad;
+				if (!ep.sk_pos) {                                           // uniform: the cell's reservation is `distinct` places
+					for (uint32_t base = 0; base < distinct; base += NT) {      // (uniform trips)
+						const uint32_t i = base + tid;
+						const bool valid = i < distinct;
+						const uint32_t rel = valid ? colof[i] : 0u;
+						double v = 1.0;
+						if (valid) { v = acc[i]; acc[i] = 0.0; }
+						if (PAT) v = pat_fix_wave(valid && !(fabs(v) > pthr), v, (int32_t)(colbase + rel), m, tile.beg, tile.end);
+						const bool ok = !valid || (plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v));
+						if (valid) { sk.out_i[o + i] = rowid; sk.out_j[o + i] = ok ? (int32_t)(colbase + rel) : -1; sk.out_v[o + i] = v; }
+						if (!ok) ++nbad;
 					}
-					uint32_t at = i;
-					if (any_bad) {                                          // uniform
-						uint32_t tot;
-						const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);
-						at = run + ex;
-						run += tot;
+					any_bad = __syncthreads_or((int)nbad);
+					if (any_bad) {                                              // uniform, rare
+						for (uint32_t ibase = 0; ibase < distinct; ibase += NT) {
+							const uint32_t i = ibase + tid;
+							int32_t col = -1; double v = 0;
+							if (i < distinct) { col = sk.out_j[o + i]; v = sk.out_v[o + i]; }
+							const bool ok = col >= 0;
+							uint32_t tot;
+							const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);      // (its barriers: every place of this trip is read before any is written)
+							if (ok) { sk.out_j[o + run + ex] = col; sk.out_v[o + run + ex] = v; }
+							run += tot;
+						}
 					}
-					if (ok) { sk.out_i[o + at] = rowid; sk.out_j[o + at] = (int32_t)(colbase + rel); sk.out_v[o + at] = v; }
+				} else {
+					// scalek: the reservation holds the ALLOWED columns only -- count the dropped ones first, store compacted
+					for (uint32_t base = 0; base < distinct; base += NT) {      // (uniform trips)
+						const uint32_t i = base + tid;
+						const bool valid = i < distinct;
+						const uint32_t rel = valid ? colof[i] : 0u;
+						double v = valid ? acc[i] : 1.0;
+						if (PAT) {
+							const bool need = valid && !(fabs(v) > pthr);
+							v = pat_fix_wave(need, v, (int32_t)(colbase + rel), m, tile.beg, tile.end);
+							if (need) acc[i] = v;                               // (kept: the store loop below reads it)
+						}
+						const bool ok = !valid || (plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v));
+						if (!ok) ++nbad;
+					}
+					any_bad = __syncthreads_or((int)nbad);
+					for (uint32_t ibase = 0; ibase < distinct; ibase += NT) {
+						const uint32_t i = ibase + tid;
+						bool ok = false; double v = 0; uint32_t rel = 0;
+						if (i < distinct) {
+							rel = colof[i];
+							v = acc[i];
+							acc[i] = 0.0;
+							ok = plain ? v != 0 : emit_value(ep, a_scale, (int32_t)(colbase + rel), v, &v);
+						}
+						uint32_t at = i;
+						if (any_bad) {                                          // uniform
+							uint32_t tot;
+							const uint32_t ex = block_exclusive_scan<uint32_t, NT>(ok ? 1u : 0u, s_scan, &tot);
+							at = run + ex;
+							run += tot;
+						}
+						if (ok) { sk.out_i[o + at] = rowid; sk.out_j[o + at] = (int32_t)(colbase + rel); sk.out_v[o + at] = v; }
+					}
 				}
 				if (tid == 0) sk.segactual[seg] = any_bad ? run : distinct;
 			}
