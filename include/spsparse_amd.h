@@ -179,7 +179,8 @@ const char *spsamd_version(void);
  *   long_cap        > 0               grouping target of those rows' hash cells (cell_cap)
  *   direct_min      > 0               a window of a tile row above this is a direct cell (off: >= dense_min)
  *   tiles_v1        1 | 2 | 3         hash tiles r01 | hash tiles v2 | bitmap-rank tiles (default: chosen per call)
- *   no_tiles, no_wmajor, xcd          1: no tiles | no window-major copy of B | XCD-partitioned cell lists
+ *   no_tiles, no_wmajor               1: no tiles | no window-major copy of B
+ *   xcd                               0: one cell list for all XCDs | 1: static XCD parts (experiment) | 2: dense cells claimed from XCD parts (default)
  *   emit_path       1 | 2             COO order of a hash cell: LDS radix sort | bitonic network (default: by cell width)
  *   light_path      1                 binned light kernels even where every row is light
  *   light_two_pass  1                 all-light COO sink: count, scan, store (two compute passes) instead of one pass + gather

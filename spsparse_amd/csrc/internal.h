@@ -79,7 +79,7 @@ struct Tuning {
 	int cell_cap = 0;            // 0: default grouping target of the hash cells
 	int dense_min = 0;           // 0: default threshold above which a window becomes a dense cell
 	int no_tiles = 0;
-	int xcd = 0;
+	int xcd = 2;                     // 0: one list for all XCDs | 1: every cell list in eight static parts (experiment, slower) | 2: the dense cells' list in eight parts, claimed
 	int emit_path = 0;           // 0 auto | 1 no bitmap rank | 2 bitonic only
 	int light_path = 0;          // 0 auto | 1 generic k_light only
 	int light_two_pass = 0;      // 1: the all-light COO sink counts, scans and stores (two compute passes) instead of one pass + gather

@@ -24,7 +24,7 @@ namespace spsamd {
 // stores the same 1 (29.0 -> 28.0 ms on cfg2; the launch is bound by the B reads, not by the accumulator).
 template <int W, int NT, int MODE, bool PAT>
 __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t ncell, const uint32_t *xb, RowMeta m,
-	const uint32_t *widx, uint64_t kstride, uint64_t wstride, uint32_t narrow, EmitParams ep, SinkParams sk)
+	const uint32_t *widx, uint64_t kstride, uint64_t wstride, uint32_t narrow, EmitParams ep, SinkParams sk, uint32_t *claim_ctr)
 {
 	constexpr int NW = NT / 64;
 	constexpr int NGRP = W / 64;             // 64-slot groups per window
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	__shared__ PatCell s_pat;
 	__shared__ unsigned long long s_u64[2 * NW];
 	__shared__ double s_f64[NW];
+	__shared__ uint32_t s_claim[4];
 
 	const unsigned tid = threadIdx.x, lane = lane_id();
 	const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_id());
@@ -72,12 +73,42 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	// A tuples of cell i+1 and then its B segment bounds are loaded while cell i is processed
 	// (branch-free prefetches: indices clamped, results masked); inside a cell the A tuples of
 	// chunk c+2 and the segment bounds of chunk c+1 are in flight while chunk c is processed.
-	const CellWalk walk = cell_walk(xb, ncell);
+	// Two ways to deal the list.  STATIC: a grid stride (over the whole list, or over the XCD group's part of it).
+	// CLAIMED (claim_ctr): the list is cut into eight parts of equal estimated cost, one per XCD group (blockIdx % 8 names
+	// the workgroups that share an XCD and its L2: each L2 then holds the B slice of ITS windows only); a workgroup claims
+	// its next cell from its part's counter, and from the other parts' once its own is used up -- the static form of the
+	// same partition lost more to the parts' unequal run times than the L2 hits returned.  Claims are made three cells
+	// ahead (the atomic's answer arrives under the scan-out) and handed to the other waves through LDS.
+	constexpr uint32_t NONE = 0xFFFFFFFFu;
+	const bool claimed = claim_ctr != nullptr && xb != nullptr;
+	const CellWalk walk = cell_walk(claimed ? nullptr : xb, ncell);
 	const uint32_t stride = walk.stride, cend = walk.end;
-	const bool any_cell = walk.first < cend;
-	const uint32_t clast = any_cell ? cend - 1 : 0;
-	Cell rec1 = cells[min(walk.first, clast)];
-	Cell rec2 = cells[min(walk.first + stride, clast)];
+	const uint32_t clast = ncell ? ncell - 1 : 0;
+	uint32_t part = blockIdx.x & 7u, tried = 0;                     // (thread 0's claiming state)
+	auto claim_resolve = [&](uint32_t got) -> uint32_t {            // thread 0: a claim's answer -> a cell, or NONE
+		while (true) {
+			if (got < xb[part + 1]) return got;
+			if (++tried >= 8u) return NONE;
+			part = (part + 1u) & 7u;
+			got = atomicAdd(&claim_ctr[part * 32u], 1u);
+		}
+	};
+	uint32_t i0, i1, i2;                                            // this cell, the next, the one after (uniform)
+	if (claimed) {
+		if (tid == 0) {
+			for (int q = 0; q < 3; ++q) s_claim[q] = tried >= 8u ? NONE : claim_resolve(atomicAdd(&claim_ctr[part * 32u], 1u));
+			s_claim[3] = NONE;
+		}
+		__syncthreads();
+		i0 = s_claim[0]; i1 = s_claim[1]; i2 = NONE;                 // (the cell after the next is read from s_claim[2 + (iter & 1)] behind the cell's first barrier)
+	} else {
+		i0 = walk.first < cend ? walk.first : NONE;
+		i1 = i0 != NONE && i0 + stride < cend ? i0 + stride : NONE;
+		i2 = i1 != NONE && i1 + stride < cend ? i1 + stride : NONE;
+	}
+	i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0); i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i1); i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i2);
+	Cell rec1 = cells[min(i0, clast)];
+	Cell rec2 = cells[min(i1, clast)];
 	uint32_t nlo, nlen; double na;
 	auto seg_bounds = [&](int32_t k, uint32_t w, uint32_t &lo, uint32_t &hi) {
 		// segment of B row k in window w: [widx[k*kstride + w*wstride], widx[.. + 1]) -- the row-major index
@@ -87,15 +118,16 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	};
 	{
 		const uint32_t e = rec1.beg + tid;
-		const bool act = e < rec1.end;
-		const uint32_t ec = act ? e : rec1.beg;
+		const bool act = i0 != NONE && e < rec1.end;
+		const uint32_t ec = e < rec1.end ? e : rec1.beg;
 		uint32_t lo, hi;
 		seg_bounds(m.acol[ec], rec1.wa, lo, hi);
 		na = m.aval[ec];
 		nlo = lo; nlen = act ? hi - lo : 0u;
 	}
 	__syncthreads();
-	for (uint32_t ci = walk.first; ci < cend; ci += stride) {
+	uint32_t iter = 0;
+	for (; i0 != NONE; ++iter, i0 = i1, i1 = i2, i2 = (claimed || i2 == NONE || i2 + stride >= cend) ? (claimed ? i2 : NONE) : i2 + stride) {
 		const Cell cell = rec1;
 		const uint32_t w = cell.wa;
 		const uint32_t beg = cell.beg, end = cell.end;
@@ -104,9 +136,9 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		const uint32_t wbase = w << WSHIFT;
 		uint32_t lo = nlo, len = nlen; double a = na;               // chunk 0, prefetched
 		rec1 = rec2;
-		rec2 = cells[min(ci + 2 * stride, clast)];
+		if (!claimed) rec2 = cells[min(i2, clast)];                 // (claimed: once this cell's first barrier has published i2's successor ... see below)
 		const uint32_t ne = rec1.beg + tid;
-		const bool nact = (ci + stride < cend) && ne < rec1.end;
+		const bool nact = i1 != NONE && ne < rec1.end;
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
@@ -144,6 +176,10 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			STAMP(0);
 			lds_barrier();                                          // B1: also orders the previous chunk's / cell's LDS traffic
 			STAMP(1);
+			if (claimed && chunk == beg) {                          // uniform: the cell after the next, claimed during the previous cell
+				i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_claim[2 + (iter & 1u)]);
+				rec2 = cells[min(i2, clast)];
+			}
 			uint32_t baseL = 0, baseN = 0, total = 0, nzc = 0;
 #pragma unroll
 			for (int q = 0; q < NW; ++q) {
@@ -299,6 +335,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		}
 		if (ABL(ep, 16)) continue;
 		STAMP(0);
+		uint32_t claim_pending = NONE;
+		if (claimed && tid == 0 && tried < 8u) claim_pending = atomicAdd(&claim_ctr[part * 32u], 1u);     // (answered under the scan-out)
 		// ---- scan-out: wave wv owns groups [wv*GPW, (wv+1)*GPW) -> ascending columns.  (The last barrier of the
 		// chunk loop, B3, has every accumulate of this cell behind it; a cell with no product at all skips it and
 		// scans zeros, which is still ordered by the next cell's B1.)
@@ -401,6 +439,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		}
 		STAMP(7);
 		if (PAT) { lds_barrier(); if (tid == 0) pat_reset(&s_pat); }     // every thread has read the cell's record
+		if (claimed && tid == 0) s_claim[2 + ((iter + 1u) & 1u)] = tried < 8u ? claim_resolve(claim_pending) : NONE;
 	}
 #ifdef SPSAMD_STAMPS
 	if (tid == 0 && sk.stamps) for (int i = 0; i < 12; ++i) sk.stamps[(size_t)blockIdx.x * 12 + i] = st_[i];
@@ -408,10 +447,21 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	if (MODE == MODE_DIGEST) digest_flush<NT>(sk.digest, d_cnt, d_hash, d_sum, s_u64, s_f64);
 }
 
+__global__ void k_claim_init(const uint32_t *xb, uint32_t *ctr)
+{
+	if (threadIdx.x < 8) ctr[threadIdx.x * 32u] = xb[threadIdx.x];
+}
+
 template <int MODE>
 void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const EmitParams &ep, const SinkParams &sk)
 {
 	if (!hv.ncell[CLS_DENSE]) return;
+	uint32_t *claim = nullptr;
+	if (c->tune.xcd == 2 && hv.xb[CLS_DENSE]) {                     // the list in eight parts, cells claimed from per-part counters
+		claim = c->arena.get<uint32_t>(8 * 32);
+		k_claim_init<<<dim3(1), dim3(64), 0, c->stream>>>(hv.xb[CLS_DENSE], claim);
+		SPS_LAUNCH_CHECK();
+	}
 	RowMeta m = m0;
 	const uint32_t *widx = hv.bwin;
 	uint64_t kstride = hv.nwin1, wstride = 1;
@@ -424,7 +474,7 @@ void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const
 		SinkParams sk2 = sk;
 		sk2.stamps = c->arena.get<unsigned long long>((size_t)grid * 12);
 		fill_zero(c, sk2.stamps, (size_t)grid * 12 * sizeof(unsigned long long));
-		k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk2);
+		k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk2, claim);
 		{
 			std::vector<unsigned long long> h((size_t)grid * 12);
 			SPS_HIP(hipMemcpyAsync(h.data(), sk2.stamps, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -438,13 +488,13 @@ void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const
 		}
 		return;
 #endif
-		if (ep.pattern) k_dense<8192, 512, MODE, true><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
-		else k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		if (ep.pattern) k_dense<8192, 512, MODE, true><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk, claim);
+		else k_dense<8192, 512, MODE, false><<<dim3(grid), dim3(512), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk, claim);
 	} else {
 		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu);
 		if (grid >= 64) grid &= ~7u;
-		if (ep.pattern) k_dense<16384, 1024, MODE, true><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
-		else k_dense<16384, 1024, MODE, false><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk);
+		if (ep.pattern) k_dense<16384, 1024, MODE, true><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk, claim);
+		else k_dense<16384, 1024, MODE, false><<<dim3(grid), dim3(1024), 0, c->stream>>>(hv.cells[CLS_DENSE], hv.ncell[CLS_DENSE], hv.xb[CLS_DENSE], m, widx, kstride, wstride, narrow, ep, sk, claim);
 	}
 	SPS_LAUNCH_CHECK();
 }

@@ -705,11 +705,16 @@ void heavy_sort_lists(spsamd_ctx *c, Heavy &hv)
 		SPS_LAUNCH_CHECK();
 		hv.cells[k] = sorted;
 	}
-	// Measured on R-MAT scale-20: giving each XCD its own part of the list is SLOWER (dense 80 vs
-	// 57 ms, hash 73 vs 62 ms) than letting all XCDs walk the same windows together, so the
-	// partition stays an experiment behind SPSAMD_XCD=1.
-	const bool xcd_aware = c->tune.xcd != 0;
-	for (int k = 0; k < NCLS && xcd_aware; ++k) {
+	// XCD parts of the (window-major) lists: eight contiguous parts of equal estimated cost, part x for the workgroups with
+	// blockIdx % 8 == x, which share an XCD and its L2.  Walked STATICALLY (part x only by group x) this is slower than one
+	// list for all (round 1: dense 80 vs 57 ms, hash 73 vs 62; round 3: dense 47 vs 33 although the L2 misses halve -- the
+	// parts' run times differ); the dense cells' list is therefore CLAIMED (k_dense: per-part counters, other parts' cells
+	// once the own part is used up: 33.1 -> 30.0 ms, L2 hit rate 51 -> 85 %).  The tiles gain nothing (a tile's B rows span
+	// 16 windows of the row-major copy: 36 -> 41 % hits) and the hash cells' list is short: both keep one list.
+	// SPSAMD_XCD / "xcd": 0 one list, 1 static parts for every class (the experiment), 2 (default) claimed parts for the dense cells.
+	const int xmode = c->tune.xcd;
+	for (int k = 0; k < NCLS && xmode != 0; ++k) {
+		if (xmode == 2 && k != CLS_DENSE) continue;
 		uint32_t nd = hv.ncell[k];
 		if (nd < 4096) continue;
 		uint32_t *cost = c->arena.get<uint32_t>(nd);
