@@ -468,7 +468,9 @@ void launch_heavy_dense(spsamd_ctx *c, const Heavy &hv, const RowMeta &m0, const
 	if (hv.wptr) { widx = hv.wptr; kstride = 1; wstride = hv.nrowb; m.btup = hv.btw; }
 	const uint32_t narrow = ((uint64_t)hv.nnzb + DENSE_R) * 12u < (uint64_t(1) << 32) ? 1u : 0u;    // 32-bit byte offsets into B suffice
 	if (hv.W == 8192) {
-		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * 2u);      // (COUNT would fit four per CU: measured 28.0 / 31.2 / 33.2 ms at two / three / four -- the B reads' L2 share)
+		unsigned grid = std::min<unsigned>(hv.ncell[CLS_DENSE], (unsigned)c->num_cu * (MODE == MODE_COUNT ? 3u : 2u));
+		// (COUNT's 20 KB of LDS allow more than two workgroups per CU.  One list for all XCDs: 28.0 / 31.2 / 33.2 ms at two / three / four -- more
+		// cells in flight, fewer L2 hits; with the claimed XCD parts: 23.5 / 20.8 / 20.9)
 		if (grid >= 64) grid &= ~7u;
 #ifdef SPSAMD_STAMPS
 		SinkParams sk2 = sk;

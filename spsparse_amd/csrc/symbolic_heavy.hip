@@ -658,6 +658,22 @@ void heavy_cells(spsamd_ctx *c, Heavy &hv, const RowMeta &m, const uint32_t *seg
 	k_cells<true><<<dim3(grid_for(hv.n, 128)), dim3(128), 0, st>>>(hv.rows, hv.n, m.beg, m.id, hv.winprod, hv.nwin, hv.cell_cap, hv.dense_min, hv.cnt, nullptr, hv.base, lists, segbase, nullptr, tile_kinds(hv));
 	SPS_LAUNCH_CHECK();
 	SPS_HIP(hipEventRecord(c->ev_side2[0], st));
+	if (c->tune.trace && hv.ntile) {
+		// what the tiles' index probes touch: per (tile, A tuple) the row's window entries from the first cell's wa to the last cell's wb
+		std::vector<Tile> ht(hv.ntile); std::vector<TCell> hc(hv.ntcell);
+		SPS_HIP(hipMemcpyAsync(ht.data(), hv.tb.tiles, ht.size() * sizeof(Tile), hipMemcpyDeviceToHost, st));
+		SPS_HIP(hipMemcpyAsync(hc.data(), hv.tb.tcells, hc.size() * sizeof(TCell), hipMemcpyDeviceToHost, st));
+		SPS_HIP(hipStreamSynchronize(st));
+		double sumL = 0, probes = 0, lines = 0, prods = 0, spanw = 0;
+		for (const Tile &t : ht) {
+			const double L = t.end - t.beg;
+			const uint32_t wa = hc[t.first].wa, wb = hc[t.first + t.ncells - 1].wb;
+			sumL += L; probes += L * t.ncells; prods += t.prods; spanw += wb - wa;
+			lines += L * ((double)((wb - wa + 1) * 4 + 127) / 128.0 + 0.5);
+		}
+		fprintf(stderr, "tiles %u cells %u: mean L %.1f, cells per tile %.2f, windows per tile %.1f, probe threads %.3g, index lines (128 B) %.3g = %.1f GB, products %.3g\n",
+			hv.ntile, hv.ntcell, sumL / hv.ntile, (double)hv.ntcell / hv.ntile, spanw / hv.ntile, probes, lines, lines * 128 / 1e9, prods);
+	}
 }
 
 // The lists are put in window-major order by some fifty small launches -- a quarter of a millisecond of launch latency
