@@ -649,6 +649,27 @@ def test_coo_emission_paths_agree(ctx, path):
     assert got[3].cells_hash > 0 and got[3].rows_mid > 0
 
 
+@pytest.mark.parametrize("xcd", [0, 1, 2])
+def test_dense_cell_walks_agree(ctx, xcd):
+    """The three ways the dense cells' list is dealt to the workgroups -- one list with a grid stride, eight static XCD
+    parts, eight parts claimed from counters (the default; cells are claimed three ahead and stolen from other parts at
+    the end) -- give the oracle's tuples in the oracle's order, in both passes of the COO sink and in the digest."""
+    from spsparse_amd import capi
+    a = wl.rmat(16, seed=3)
+    A = orc.Mat(*a)
+    want = orc.multiply(A, A, rowwise=True, nthreads=8)
+    ctx.set_tuning("xcd", xcd)
+    try:
+        got = _dev(ctx, A, A)
+        _, _, _, d = _dev(ctx, A, A, sink=capi.SINK_DIGEST)
+    finally:
+        ctx.set_tuning("xcd", 2)
+    _check(got, want)
+    assert got[3].cells_dense >= 4096                         # (below that the list is not cut into parts)
+    cnt, s_, h = orc.digest(*want[:3])
+    assert d.nnz == cnt and d.hash == h and abs(d.sum - s_) <= 1e-11 * abs(s_)
+
+
 @pytest.mark.parametrize("knobs", [
     {"tiles_v1": 1}, {"tiles_v1": 2}, {"tiles_v1": 3}, {"no_tiles": 1},
     {"direct_min": 1024}, {"direct_min": 1024, "tiles_v1": 2},
