@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 	// same partition lost more to the parts' unequal run times than the L2 hits returned.  Claims are made three cells
 	// ahead (the atomic's answer arrives under the scan-out) and handed to the other waves through LDS.
 	constexpr uint32_t NONE = 0xFFFFFFFFu;
-	const bool claimed = claim_ctr != nullptr && xb != nullptr;
+	const bool claimed = claim_ctr != nullptr && xb != nullptr && !ABL(ep, 16);       // (the no-scan-out ablation skips the end of the cell, where claims are published)
 	const CellWalk walk = cell_walk(claimed ? nullptr : xb, ncell);
 	const uint32_t stride = walk.stride, cend = walk.end;
 	const uint32_t clast = ncell ? ncell - 1 : 0;
