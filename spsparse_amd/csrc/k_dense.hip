@@ -107,27 +107,10 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		i2 = i1 != NONE && i1 + stride < cend ? i1 + stride : NONE;
 	}
 	i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0); i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i1); i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i2);
-	// A cell's record is read two cells ahead and must STAY in flight until it is needed: read through a uniform address the
-	// compiler moves it to scalar registers at once (global_load, s_waitcnt vmcnt(0), v_readfirstlane -- a full memory latency
-	// per cell for every wave, and the other prefetches' depth with it).  So the address gets a per-lane zero the compiler
-	// cannot see through, the fields wait in vector registers, and they are made scalar when the record's turn comes.
-	uint32_t zlane = 0;
-	asm volatile("" : "+v"(zlane));
-	struct PendRec { uint32_t beg, end, rowid, seg, wab; };
-	auto load_rec = [&](uint32_t idx) -> PendRec {
-		const uint32_t *p = reinterpret_cast<const uint32_t *>(cells + min(idx, clast)) + zlane;
-		return PendRec{p[0], p[1], p[2], p[3], p[5]};
-	};
-	auto uniform_rec = [&](const PendRec &r) -> Cell {
-		Cell c;
-		c.beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.beg); c.end = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.end);
-		c.rowid = __builtin_amdgcn_readfirstlane((int)r.rowid); c.seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.seg);
-		const uint32_t wab = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.wab);
-		c.wa = (uint16_t)(wab & 0xFFFFu); c.wb = (uint16_t)(wab >> 16); c.prods = 0; c.pad[0] = c.pad[1] = 0;
-		return c;
-	};
+	// (the records read ahead stay in flight in vector registers: CellPend, spgemm_dev.h)
+	const uint32_t zlane = cell_pend_zero();
 	Cell rec1 = cells[min(i0, clast)];
-	PendRec pend2 = load_rec(i1);
+	CellPend pend2 = cell_pend_load(cells, min(i1, clast), zlane);
 	uint32_t nlo, nlen; double na;
 	auto seg_bounds = [&](int32_t k, uint32_t w, uint32_t &lo, uint32_t &hi) {
 		// segment of B row k in window w: [widx[k*kstride + w*wstride], widx[.. + 1]) -- the row-major index
@@ -154,8 +137,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		const double a_scale = row_scale(ep, rowid);
 		const uint32_t wbase = w << WSHIFT;
 		uint32_t lo = nlo, len = nlen; double a = na;               // chunk 0, prefetched
-		rec1 = uniform_rec(pend2);
-		if (!claimed) pend2 = load_rec(i2);                         // (claimed: once this cell's first barrier has published i2's successor ... see below)
+		rec1 = cell_from_pend(pend2);
+		if (!claimed) pend2 = cell_pend_load(cells, min(i2, clast), zlane);                         // (claimed: once this cell's first barrier has published i2's successor ... see below)
 		const uint32_t ne = rec1.beg + tid;
 		const bool nact = i1 != NONE && ne < rec1.end;
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
@@ -197,7 +180,7 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 			STAMP(1);
 			if (claimed && chunk == beg) {                          // uniform: the cell after the next, claimed during the previous cell
 				i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_claim[2 + (iter & 1u)]);
-				pend2 = load_rec(i2);
+				pend2 = cell_pend_load(cells, min(i2, clast), zlane);
 			}
 			uint32_t baseL = 0, baseN = 0, total = 0, nzc = 0;
 #pragma unroll

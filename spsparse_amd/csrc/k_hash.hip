@@ -37,8 +37,9 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 	const uint32_t stride = walk.stride, cend = walk.end;
 	const bool any_cell = walk.first < cend;
 	const uint32_t clast = any_cell ? cend - 1 : 0;
+	const uint32_t zlane = cell_pend_zero();                        // (records read ahead stay in flight in vector registers: CellPend)
 	Cell rec1 = cells[min(walk.first, clast)];
-	Cell rec2 = cells[min(walk.first + stride, clast)];
+	CellPend pend2 = cell_pend_load(cells, min(walk.first + stride, clast), zlane);
 	uint32_t nlo, nlen; double na;
 	{
 		const uint32_t e = rec1.beg + tid;
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(NT) void k_hash(const Cell *cells, uint32_t ncell, 
 		const int32_t rowid = cell.rowid;
 		const uint32_t lo0 = nlo, len0 = nlen; const double a0 = na;
 		// stage A / B of the pipeline
-		rec1 = rec2;
-		rec2 = cells[min(ci + 2 * stride, clast)];
+		rec1 = cell_from_pend(pend2);
+		pend2 = cell_pend_load(cells, min(ci + 2 * stride, clast), zlane);
 		const uint32_t ne = rec1.beg + tid;
 		const bool nact = (ci + stride < cend) && ne < rec1.end;
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;

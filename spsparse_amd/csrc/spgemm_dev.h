@@ -439,6 +439,28 @@ struct __attribute__((packed, aligned(4))) BPiece { uint32_t w[3 * DENSE_R]; };
 // in window-major order, is cut into 8 contiguous parts of equal cost (xb[0..8]); XCD group
 // x walks part x, so each L2 holds the B column-window slice of ITS part only instead of all
 // eight L2s fetching the same slice.  Speed only: any placement gives the same result.
+// A cell's record, read ahead of its turn, must STAY in flight: read through a uniform address the compiler moves it to
+// scalar registers at once (global_load, s_waitcnt vmcnt(0), v_readfirstlane -- a memory latency per cell for every wave, and
+// every other load in flight drained with it).  So the address gets a per-lane zero the compiler cannot see through
+// (cell_pend_zero), the words wait in vector registers (CellPend), and they are made scalar when the record's turn comes.
+struct CellPend { uint32_t w[6]; };
+__device__ __forceinline__ uint32_t cell_pend_zero() { uint32_t z = 0; asm volatile("" : "+v"(z)); return z; }
+__device__ __forceinline__ CellPend cell_pend_load(const Cell *cells, uint32_t idx, uint32_t zlane)
+{
+	const uint32_t *p = reinterpret_cast<const uint32_t *>(cells + idx) + zlane;
+	return CellPend{{p[0], p[1], p[2], p[3], p[4], p[5]}};
+}
+__device__ __forceinline__ Cell cell_from_pend(const CellPend &r)
+{
+	Cell c;
+	c.beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w[0]); c.end = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w[1]);
+	c.rowid = __builtin_amdgcn_readfirstlane((int)r.w[2]); c.seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w[3]);
+	c.prods = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w[4]);
+	const uint32_t wab = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w[5]);
+	c.wa = (uint16_t)(wab & 0xFFFFu); c.wb = (uint16_t)(wab >> 16); c.pad[0] = c.pad[1] = 0;
+	return c;
+}
+
 struct CellWalk { uint32_t first, end, stride; };
 __device__ __forceinline__ CellWalk cell_walk(const uint32_t *xb, uint32_t ncell)
 {
