@@ -144,9 +144,11 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
-		// in-cell prefetch, stage A: the A tuple of chunk 1
-		int32_t kA = 0; double aA = 0.0;
-		if (beg + NT < end) {                                       // uniform
+		// in-cell prefetch, stage A: the A tuple of chunk 1.  Branch-free like the prefetches across cells (a tuple past the
+		// row's end re-reads the row's first): a load inside a conditional -- even a uniform one -- is waited for at the join,
+		// i.e. at once
+		int32_t kA; double aA;
+		{
 			const uint32_t e1 = beg + NT + tid;
 			const uint32_t e1c = e1 < end ? e1 : beg;
 			kA = m.acol[e1c]; aA = m.aval[e1c];
@@ -157,16 +159,14 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		for (uint32_t chunk = beg; chunk < end; chunk += NT) {
 			STAMP_COUNT(9);
 			// stage B for chunk c+1 (its k arrived during chunk c-1), stage A for chunk c+2
-			uint32_t lo2 = 0, hi2 = 0; double a2 = 0.0;
-			if (chunk + NT < end) {                                 // uniform
+			uint32_t lo2, hi2; double a2;
+			{
 				seg_bounds(kA, w, lo2, hi2);
 				a2 = aA;
-				if (chunk + NT + tid >= end) hi2 = lo2;
-				if (chunk + 2 * NT < end) {
-					const uint32_t e2 = chunk + 2 * NT + tid;
-					const uint32_t e2c = e2 < end ? e2 : beg;
-					kA = m.acol[e2c]; aA = m.aval[e2c];
-				}
+				if (chunk + NT + tid >= end) hi2 = lo2;             // (also: no next chunk at all)
+				const uint32_t e2 = chunk + 2 * NT + tid;
+				const uint32_t e2c = e2 < end ? e2 : beg;
+				kA = m.acol[e2c]; aA = m.aval[e2c];
 			}
 			// ---- compact the non-empty segments, item prefix, first-item bits
 			const uint32_t items = (len + R - 1) / R;
