@@ -127,6 +127,12 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		na = m.aval[ec];
 		nlo = lo; nlen = act ? hi - lo : 0u;
 	}
+	int32_t nkA; double naA;                                        // the A tuple of the next cell's chunk 1 (a tuple past the row's end re-reads its first)
+	{
+		const uint32_t e1 = rec1.beg + NT + tid;
+		const uint32_t e1c = e1 < rec1.end ? e1 : rec1.beg;
+		nkA = m.acol[e1c]; naA = m.aval[e1c];
+	}
 	__syncthreads();
 	uint32_t iter = 0;
 	for (; i0 != NONE; ++iter, i0 = i1, i1 = i2, i2 = (claimed || i2 == NONE || i2 + stride >= cend) ? (claimed ? i2 : NONE) : i2 + stride) {
@@ -144,14 +150,15 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 		const uint32_t nec = ne < rec1.end ? ne : rec1.beg;
 		const int32_t nk = m.acol[nec];
 		na = m.aval[nec];
-		// in-cell prefetch, stage A: the A tuple of chunk 1.  Branch-free like the prefetches across cells (a tuple past the
-		// row's end re-reads the row's first): a load inside a conditional -- even a uniform one -- is waited for at the join,
-		// i.e. at once
-		int32_t kA; double aA;
+		// in-cell prefetch, stage A: the A tuple of chunk 1 was requested a cell ago, with the cell's first chunk (its k is
+		// needed at the top of chunk 0 for the segment bounds of chunk 1: requested here, the wait for it would come right
+		// behind this cell's other prefetches and drain them all); the next cell's is requested now.  Branch-free like every
+		// prefetch here: a load inside a conditional -- even a uniform one -- is waited for at the join, i.e. at once
+		int32_t kA = nkA; double aA = naA;
 		{
-			const uint32_t e1 = beg + NT + tid;
-			const uint32_t e1c = e1 < end ? e1 : beg;
-			kA = m.acol[e1c]; aA = m.aval[e1c];
+			const uint32_t e1 = rec1.beg + NT + tid;
+			const uint32_t e1c = e1 < rec1.end ? e1 : rec1.beg;
+			nkA = m.acol[e1c]; naA = m.aval[e1c];
 		}
 
 		STAMP_COUNT(8);
