@@ -1,7 +1,7 @@
-"""Developer tool (GPU box): R-MAT A*A at several seeds and scales against the oracle's streaming digest -- whole-product
+"""Test tool (GPU box; not collected by pytest): R-MAT A*A at several seeds and scales against the oracle's streaming digest -- whole-product
 count / index hash / per-row counts and hashes in the digest sink and in both passes of the COO sink.
 
-    python scripts/soak_rmat.py [scale] [seeds, e.g. 2,3,4]
+    python tests/soak_rmat.py [scale] [seeds, e.g. 2,3,4]
 """
 import sys
 
