@@ -1,4 +1,4 @@
-"""Developer tool: one-off full tuple-by-tuple comparison against the row-wise oracle at a larger R-MAT scale
+"""Test tool (not collected by pytest; was scripts/compare_big.py): one-off full tuple-by-tuple comparison against the row-wise oracle at a larger R-MAT scale
 than the test suite uses (needs the host cores and memory of the GPU box)."""
 import sys
 import time
