@@ -46,6 +46,11 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
                 if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
                     src = open(os.path.join(dp, f), errors="ignore").read()
                     assert "oracle" not in src.replace("test oracle", "").replace("the oracle's", ""), os.path.join(dp, f)
+    # ... and the developer scripts may not import it either (checkers that need it live under tests/)
+    for f in os.listdir(os.path.join(ROOT, "scripts")):
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "scripts", f), errors="ignore").read()
+            assert "import orc" not in src and "from oracle" not in src and "oracle/" not in src, f
 
 
 def _build_shim_test(tmp_path):
