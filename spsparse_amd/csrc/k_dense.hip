@@ -302,7 +302,8 @@ __global__ __launch_bounds__(NT, 4) void k_dense(const Cell *cells, uint32_t nce
 #if DENSE_DEPTH == 2
 				// two pieces in flight: the loads of step s+1 are issued before the products of step s are
 				// accumulated, the lookup of step s+2 runs under them.  (Not the default: no faster -- nor is the ping-pong form,
-				// two named register sets and the loop unrolled by two so that no piece is copied: 29.6 against 29.0 ms.)
+				// two named register sets and the loop unrolled by two so that no piece is copied, every load and lookup outside
+				// conditionals so that the accumulate waits with vmcnt(3): 28.9 against 28.0 ms -- the L1 fill path is the bound, not the latency.)
 				uint32_t bp0, nv0, bp1 = 0, nv1 = 0; double av0, av1 = 0.0;
 				lookup(0, bp0, nv0, av0);
 				BPiece p0 = fetch(bp0), p1 = p0;
