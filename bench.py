@@ -598,9 +598,14 @@ def roofline_of(args, world, results, scale_is_cfg2):
                 PMC_FILE, pmc.get("command", "python bench.py"), pmc.get("commit", "?"))
     except (OSError, KeyError, ValueError):
         traffic = None
+    # (the kernel that moves the most algorithmic bytes, named beside the longest one: since round 3 they are two kernels)
+    big = max(kernels, key=lambda k: 16 * k[3] + 12 * k[2])
+    big_bytes = 16 * big[3] + 12 * big[2]
     return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
             "alg_bytes_per_launch": alg_bytes, "ms_per_launch": ms_kernel,
+            "most_bytes_kernel": {"kernel": big[0], "ms_per_launch": big[1], "alg_bytes_per_launch": int(big_bytes),
+                                  "frac": big_bytes / (big[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS if big[1] > 0 else None},
             "all_kernels": {k[0]: {"ms": k[1], "products": int(k[2]),
                                    "frac": (16 * k[3] + 12 * k[2]) / (k[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS if k[1] > 0 else None} for k in kernels}}
 
