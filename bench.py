@@ -578,8 +578,8 @@ def roofline_of(args, world, results, scale_is_cfg2):
         ("k_hash(rows)", avg(lambda r: r.ms_mid), res.products_mid, res.tuples_mid),
         ("k_light", avg(lambda r: r.ms_light), res.products_light, res.tuples_light),
     ]
-    # dominant = longest; kernels within 3 % of the longest count as tied (k_dense and the tile kernel take 32.5 and 32.2 ms
-    # of a cfg2 step) and the tie goes to the one that moves more algorithmic bytes, so that the headline figure does not
+    # dominant = longest; kernels within 3 % of the longest count as tied (k_dense and the tile kernel took 32.5 and 32.2 ms
+    # of a cfg2 step in round 2; 28.1 and 31.9 since round 3) and the tie goes to the one that moves more algorithmic bytes, so that the headline figure does not
     # flip between two kernels with the run-to-run noise.  all_kernels lists every kernel either way.
     t_max = max(k[1] for k in kernels)
     name, ms_kernel, k_prod, k_tup = max((k for k in kernels if k[1] >= 0.97 * t_max), key=lambda k: 16 * k[3] + 12 * k[2])
